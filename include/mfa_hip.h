@@ -1,0 +1,103 @@
+/* C-ABI of the MI355X match path (libmfa_hip.so).
+ *
+ * This is the drop-in boundary for the reference's match loop: everything the
+ * reference does between "automaton compiled" and "0/1 per string" --
+ *     bool MFA::match(string)              reference automata.h:69, mfa.cpp:215-236
+ *     bool Automata::match(const string&)  reference automata.h:42, automata.cpp:177-210
+ *     the per-string loops that call them  reference matchers/match.cpp:21-31,
+ *                                          matchers/match_mfa.cpp:28-36,72-80
+ * -- for a whole batch of strings at once, on the GPU.  The reference has no FFI
+ * of its own (it is one C++ process); these are the entry points its
+ * `Automata`/`MFA` classes bind when the match loop is moved to the device (the
+ * binding is shown in INTEGRATION.md, our own host mirror of those classes lives in
+ * re2-modification_amd/host/).
+ *
+ * Plain C types only: pointers and sizes.  No exceptions cross this boundary;
+ * every function returns 0 (MFA_OK) or a negative MFA_ERR_* code.  The caller owns
+ * every buffer it passes.  Functions are re-entrant per (image, device, stream);
+ * one image may be used from several host threads as long as they use different
+ * streams or serialise their calls.
+ *
+ * There is NO CPU fallback: without a usable HIP device the match entry points
+ * return MFA_ERR_NO_DEVICE.
+ */
+#ifndef MFA_HIP_H
+#define MFA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mfa_image_format.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MFA_OK                 0
+#define MFA_ERR_INVALID_ARG   -1  /* NULL pointer, bad size                                            */
+#define MFA_ERR_BAD_BLOB      -2  /* blob fails the format checks of mfa_image_format.h                */
+#define MFA_ERR_UNSUPPORTED   -3  /* well-formed automaton outside the kernels' limits (see below)     */
+#define MFA_ERR_NO_DEVICE     -4  /* no HIP device / device index out of range                         */
+#define MFA_ERR_HIP           -5  /* a HIP runtime call failed; mfa_last_hip_error() has the code       */
+#define MFA_ERR_NOMEM         -6
+#define MFA_ERR_TOO_LONG      -7  /* a string is longer than MFA_MAX_STRING_BYTES                       */
+
+/* limits of the device kernels (violations -> MFA_ERR_UNSUPPORTED at image creation) */
+#define MFA_MAX_NODES        128u      /* MFA kind: nodes                                  */
+#define MFA_MAX_DEGREE       31u       /* MFA kind: out-edges per node                     */
+#define MFA_MAX_KERNEL_CELLS 4u        /* MFA kind: distinct memory cells                  */
+#define MFA_MAX_DFA_STATES   4096u     /* NFA kind: reachable state sets after tabulation  */
+#define MFA_MAX_STRING_BYTES 0x00ffffffu /* 16 MiB - 1 per string                          */
+
+typedef struct mfa_image mfa_image_t;
+
+typedef struct mfa_image_info {
+    uint32_t kind;         /* MFA_KIND_NFA / MFA_KIND_MFA                                   */
+    uint32_t is_reversed;
+    uint32_t n_nodes, n_edges, n_cells;
+    uint32_t dfa_states;   /* NFA kind: number of tabulated state sets (incl. the dead set) */
+    uint32_t byte_classes; /* NFA kind: number of input byte classes                        */
+    uint32_t reserved;
+} mfa_image_info;
+
+/* Build an image from a blob (include/mfa_image_format.h).  Host-only work: parse,
+ * check the structural invariants the kernels rely on, and for MFA_KIND_NFA tabulate
+ * the reference's step function (automata.cpp:98-128) into a transition table.
+ * Needs no GPU.  Replaces: holding an `Automata*` / `MFA*` (automata.h:18-84). */
+int  mfa_image_create(const void* blob, size_t n_bytes, mfa_image_t** out);
+void mfa_image_destroy(mfa_image_t* img);
+int  mfa_image_get_info(const mfa_image_t* img, mfa_image_info* out);
+
+/* Upload the image's tables to `device` and allocate its launch workspace now
+ * (otherwise done by the first match call on that device). */
+int  mfa_image_prepare(mfa_image_t* img, int device);
+
+/* Match n strings; string k is bytes[offsets[k] .. offsets[k+1]).  ALL pointers are
+ * DEVICE pointers on `device` (offsets has n+1 entries; results gets n bytes, 1 =
+ * accepted, 0 = rejected -- the value `cout << match` prints, match.cpp:30).
+ * Asynchronous: work is enqueued on `stream` (a hipStream_t, NULL = default
+ * stream) and the call returns.  Replaces: the loop
+ *     while (...) { match = automata->match(text); }      match.cpp:21-31 */
+int  mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                     uint8_t* d_results, int device, void* stream);
+
+/* Same with HOST pointers: copies the batch to the device, matches, copies the
+ * results back, synchronises.  Convenience for callers that hold std::strings
+ * (the CLI); throughput is then bounded by the host link, not by the kernel. */
+int  mfa_match_batch_host(mfa_image_t* img, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
+                          uint8_t* results, int device);
+
+/* Device-side time of the last match kernel launched through this image on
+ * `device`, in milliseconds, measured with HIP events recorded on the launch stream
+ * around the kernel alone.  Synchronises on the stop event. */
+int  mfa_last_kernel_ms(mfa_image_t* img, int device, float* ms);
+
+int         mfa_device_count(void);        /* >= 0, or MFA_ERR_NO_DEVICE */
+int         mfa_last_hip_error(void);      /* hipError_t of the last failed HIP call on this thread */
+const char* mfa_strerror(int code);
+const char* mfa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MFA_HIP_H */

@@ -1,0 +1,208 @@
+// C-ABI of libmfa_hip.so (include/mfa_hip.h): glue between plain-C callers and the kernels.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <new>
+
+#include "mfa_internal.h"
+
+namespace mfa {
+
+static thread_local int g_last_hip_error = 0;
+void set_last_hip_error(int e) { g_last_hip_error = e; }
+
+#define HIP_TRY(expr)                                                   \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) { set_last_hip_error((int)e_); return MFA_ERR_HIP; } \
+    } while (0)
+
+void device_release(DeviceState& ds) {
+    if (ds.device < 0) return;
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return;
+    (void)hipSetDevice(ds.device);
+    if (ds.d_edge_begin) (void)hipFree(ds.d_edge_begin);
+    if (ds.d_edges) (void)hipFree(ds.d_edges);
+    if (ds.d_dfa_trans) (void)hipFree(ds.d_dfa_trans);
+    if (ds.d_dfa_accept) (void)hipFree(ds.d_dfa_accept);
+    if (ds.d_byte_class) (void)hipFree(ds.d_byte_class);
+    if (ds.d_counter) (void)hipFree(ds.d_counter);
+    if (ds.d_scratch) (void)hipFree(ds.d_scratch);
+    if (ds.ev_start) (void)hipEventDestroy((hipEvent_t)ds.ev_start);
+    if (ds.ev_stop) (void)hipEventDestroy((hipEvent_t)ds.ev_stop);
+    ds = DeviceState{};
+    (void)hipSetDevice(cur);
+}
+
+// caller holds img->mu
+int device_prepare(mfa_image* img, int device, DeviceState** out) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MFA_ERR_NO_DEVICE;
+    auto it = img->dev.find(device);
+    if (it != img->dev.end()) { *out = &it->second; return MFA_OK; }
+    HIP_TRY(hipSetDevice(device));
+    DeviceState ds;
+    ds.device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    ds.n_cus = prop.multiProcessorCount;
+    const HostImage& h = img->host;
+    auto up = [&](void** dst, const void* src, size_t bytes) -> int {
+        HIP_TRY(hipMalloc(dst, bytes ? bytes : 4));
+        if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+        return MFA_OK;
+    };
+    int rc = MFA_OK;
+    if (h.h.kind == MFA_KIND_MFA) {
+        rc = up((void**)&ds.d_edge_begin, h.edge_begin.data(), h.edge_begin.size() * 4);
+        if (rc == MFA_OK) rc = up((void**)&ds.d_edges, h.edges.data(), h.edges.size() * sizeof(mfa_blob_edge));
+    } else {
+        rc = up((void**)&ds.d_dfa_trans, h.dfa_trans.data(), h.dfa_trans.size() * 2);
+        if (rc == MFA_OK) rc = up((void**)&ds.d_dfa_accept, h.dfa_accept.data(), h.dfa_accept.size());
+        if (rc == MFA_OK) rc = up((void**)&ds.d_byte_class, h.byte_class, 256);
+    }
+    if (rc == MFA_OK) {
+        hipError_t e = hipMalloc((void**)&ds.d_counter, 64);
+        if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&ds.ev_start);
+        if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&ds.ev_stop);
+        if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }
+    }
+    if (rc != MFA_OK) { device_release(ds); return rc; }
+    ds.timed = true;
+    auto ins = img->dev.emplace(device, ds);
+    *out = &ins.first->second;
+    return MFA_OK;
+}
+
+}  // namespace mfa
+
+using namespace mfa;
+
+extern "C" {
+
+int mfa_image_create(const void* blob, size_t n_bytes, mfa_image_t** out) {
+    if (!blob || !out) return MFA_ERR_INVALID_ARG;
+    *out = nullptr;
+    mfa_image* img = new (std::nothrow) mfa_image();
+    if (!img) return MFA_ERR_NOMEM;
+    int rc = parse_blob(blob, n_bytes, img->host);
+    if (rc == MFA_OK) rc = img->host.h.kind == MFA_KIND_MFA ? check_mfa_invariants(img->host) : tabulate_nfa(img->host);
+    if (rc != MFA_OK) { delete img; return rc; }
+    *out = img;
+    return MFA_OK;
+}
+
+void mfa_image_destroy(mfa_image_t* img) {
+    if (!img) return;
+    for (auto& kv : img->dev) device_release(kv.second);
+    delete img;
+}
+
+int mfa_image_get_info(const mfa_image_t* img, mfa_image_info* out) {
+    if (!img || !out) return MFA_ERR_INVALID_ARG;
+    std::memset(out, 0, sizeof *out);
+    out->kind = img->host.h.kind; out->is_reversed = img->host.h.is_reversed;
+    out->n_nodes = img->host.h.n_nodes; out->n_edges = img->host.h.n_edges; out->n_cells = img->host.h.n_cells;
+    out->dfa_states = img->host.dfa_states; out->byte_classes = img->host.n_classes;
+    return MFA_OK;
+}
+
+int mfa_image_prepare(mfa_image_t* img, int device) {
+    if (!img) return MFA_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(img->mu);
+    DeviceState* ds = nullptr;
+    return device_prepare(img, device, &ds);
+}
+
+int mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
+                    int device, void* stream) {
+    if (!img || !d_offsets || (!d_results && n)) return MFA_ERR_INVALID_ARG;
+    if (n == 0) return MFA_OK;
+    std::lock_guard<std::mutex> lk(img->mu);
+    DeviceState* ds = nullptr;
+    int rc = device_prepare(img, device, &ds);
+    if (rc != MFA_OK) return rc;
+    HIP_TRY(hipSetDevice(device));
+    if (img->host.h.kind == MFA_KIND_MFA) return launch_mfa_walk(img->host, *ds, d_bytes, d_offsets, n, d_results, stream);
+    return launch_dfa_walk(img->host, *ds, d_bytes, d_offsets, n, d_results, stream);
+}
+
+int mfa_match_batch_host(mfa_image_t* img, const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* results,
+                         int device) {
+    if (!img || !offsets || (!results && n)) return MFA_ERR_INVALID_ARG;
+    if (n == 0) return MFA_OK;
+    for (uint64_t k = 0; k < n; k++) {
+        if (offsets[k + 1] < offsets[k]) return MFA_ERR_INVALID_ARG;
+        if (offsets[k + 1] - offsets[k] > MFA_MAX_STRING_BYTES) return MFA_ERR_TOO_LONG;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MFA_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    const uint64_t total = offsets[n] - offsets[0];
+    uint8_t* d_bytes = nullptr; uint64_t* d_off = nullptr; uint8_t* d_res = nullptr;
+    int rc = MFA_OK;
+    hipError_t e = hipMalloc((void**)&d_bytes, total + 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_off, (n + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_res, n);
+    if (e == hipSuccess && total) e = hipMemcpy(d_bytes, bytes + offsets[0], total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        if (offsets[0] == 0) e = hipMemcpy(d_off, offsets, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+        else {
+            uint64_t* tmp = new (std::nothrow) uint64_t[n + 1];
+            if (!tmp) rc = MFA_ERR_NOMEM;
+            else {
+                for (uint64_t k = 0; k <= n; k++) tmp[k] = offsets[k] - offsets[0];
+                e = hipMemcpy(d_off, tmp, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+                delete[] tmp;
+            }
+        }
+    }
+    if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }
+    if (rc == MFA_OK) rc = mfa_match_batch(img, d_bytes, d_off, n, d_res, device, nullptr);
+    if (rc == MFA_OK) {
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(results, d_res, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }
+    }
+    if (d_bytes) (void)hipFree(d_bytes);
+    if (d_off) (void)hipFree(d_off);
+    if (d_res) (void)hipFree(d_res);
+    return rc;
+}
+
+int mfa_last_kernel_ms(mfa_image_t* img, int device, float* ms) {
+    if (!img || !ms) return MFA_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(img->mu);
+    auto it = img->dev.find(device);
+    if (it == img->dev.end() || !it->second.timed) return MFA_ERR_INVALID_ARG;
+    HIP_TRY(hipEventSynchronize((hipEvent_t)it->second.ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)it->second.ev_start, (hipEvent_t)it->second.ev_stop));
+    return MFA_OK;
+}
+
+int mfa_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return MFA_ERR_NO_DEVICE;
+    return count;
+}
+
+int mfa_last_hip_error(void) { return g_last_hip_error; }
+
+const char* mfa_strerror(int code) {
+    switch (code) {
+        case MFA_OK: return "ok";
+        case MFA_ERR_INVALID_ARG: return "invalid argument";
+        case MFA_ERR_BAD_BLOB: return "malformed automaton image blob";
+        case MFA_ERR_UNSUPPORTED: return "automaton outside the limits of the device kernels";
+        case MFA_ERR_NO_DEVICE: return "no usable HIP device (there is no CPU fallback)";
+        case MFA_ERR_HIP: return "HIP runtime error";
+        case MFA_ERR_NOMEM: return "out of host memory";
+        case MFA_ERR_TOO_LONG: return "string longer than MFA_MAX_STRING_BYTES";
+    }
+    return "unknown error";
+}
+
+const char* mfa_version(void) { return "mfa_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,497 @@
+// HIP kernels of the match path, written for gfx950 (MI355X): 64-wide wavefronts,
+// one input string per lane, per-string automaton state in LDS (struct-of-arrays, one
+// bank per lane), the automaton itself read through the scalar cache.
+//
+//   mfa_walk_kernel  -- MFA::match (reference mfa.cpp:215-236) for a batch of strings
+//   dfa_walk_kernel  -- Automata::match (reference automata.cpp:177-210) on the tabulated
+//                       step function (image_host.cpp: tabulate_nfa)
+//
+// ---- how the MFA kernel restates mfa.cpp ---------------------------------------------------
+// The reference keeps a std::set of (pos, node, memory) states, but each step only the first
+// state per node (in set order) is evaluated and all others are dropped (mfa.cpp:206-211).
+// So a string's live state is one SLOT per automaton node, holding the minimum state for that
+// node under the set order:
+//     (pos, name of the first memory cell, allocation order of that cell's Variable).
+// Allocation order is creation order of the state (copy_memory allocates the cells when the
+// state is created, mfa.cpp:107-114), which for states created within one step is
+//     (pos of the source state, node of the source state, DFS index of the creating edge)
+// because sources are evaluated in (pos, node) order; a state re-inserted unchanged (the
+// "wait" branch, mfa.cpp:195-197) keeps its old Variables and is therefore older than every
+// state created in the current step.  Slots carry that key as three words P, Q, R.
+// Memory cell values are always contiguous spans of the scan-order input (every write appends
+// exactly the text just consumed, mfa.cpp:89-104), so a cell is (start, len, flags).
+// `finish` is reached only through epsilon edges and only kept when pos == len
+// (mfa.cpp:138-140,143-147): it is an accept flag, and once set it stays set.
+#include <hip/hip_runtime.h>
+
+#include "mfa_internal.h"
+
+namespace mfa {
+
+#define HIP_TRY(expr)                                                   \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) { set_last_hip_error((int)e_); return MFA_ERR_HIP; } \
+    } while (0)
+
+static constexpr uint32_t kEmpty = 0xffffffffu;
+
+// flags word of a slot: per cell c (0-based) 8 bits at 8*c
+static constexpr uint32_t F_PRESENT = 1u, F_OPEN = 2u, F_READ = 4u, F_UNI = 8u;   // + char in bits 8..15 of a 16-bit field
+// With K <= 4 cells we use two flag words of 2 x 16 bits: cell c lives in word c/2, bits 16*(c%2)..
+
+template <int K>
+struct Mem {                 // the memory of one state, in registers
+    uint32_t start[K];
+    uint32_t len[K];
+    uint32_t fl[K];          // F_* | ch << 8
+};
+
+struct DevImg {
+    const uint32_t* edge_begin;
+    const uint2*    edges;
+    uint32_t n_nodes, start, finish, reversed;
+};
+
+// ---- LDS slot arrays --------------------------------------------------------------------------
+// word index of (buf, node, w) for this lane:  (((buf * N + node) * W + w) * 64 + lane
+template <int K>
+struct SlotLayout {
+    static constexpr int W = 3 + 3 * K;      // P, Q, R, then per cell start, len, flags
+};
+
+template <int K, bool LDS_SLOTS>
+struct Slots {
+    uint32_t* base;          // LDS or global scratch, already offset to this wave and lane
+    uint32_t  N;
+    __device__ __forceinline__ uint32_t* at(uint32_t buf, uint32_t node, uint32_t w) const {
+        return base + (((buf * N + node) * SlotLayout<K>::W + w) << 6);
+    }
+};
+
+template <int K>
+__device__ __forceinline__ uint32_t first_name(const Mem<K>& m) {
+#pragma unroll
+    for (int c = 0; c < K; c++)
+        if (m.fl[c] & F_PRESENT) return (uint32_t)(c + 1);
+    return 0u;
+}
+
+// ---- input access -------------------------------------------------------------------------------
+struct Input {
+    const uint8_t* bytes;    // whole batch
+    uint64_t       base;     // offset of this lane's string
+    uint32_t       len;
+    // one cached aligned 16-byte block
+    uint64_t       blk;      // byte offset of the cached block (multiple of 16), ~0 = none
+    uint4          data;
+};
+
+template <bool REV>
+__device__ __forceinline__ uint64_t scan_addr(const Input& in, uint32_t j) {
+    return in.base + (REV ? (uint64_t)(in.len - 1u - j) : (uint64_t)j);
+}
+
+__device__ __forceinline__ uint32_t cached_byte(Input& in, uint64_t addr) {
+    uint64_t blk = addr & ~(uint64_t)15;
+    if (blk != in.blk) {
+        in.data = *reinterpret_cast<const uint4*>(in.bytes + blk);
+        in.blk = blk;
+    }
+    uint32_t o = (uint32_t)addr & 15u;
+    uint32_t w = (o & 8u) ? ((o & 4u) ? in.data.w : in.data.z) : ((o & 4u) ? in.data.y : in.data.x);
+    return (w >> ((o & 3u) * 8u)) & 0xffu;
+}
+
+// equality of scan[a, a+l) and scan[b, b+l): the two value spans of a cell read (mfa.cpp:179-191)
+template <bool REV>
+__device__ __forceinline__ bool spans_equal(const Input& in, uint32_t a, uint32_t b, uint32_t l) {
+    // in memory both spans are ascending byte ranges
+    const uint8_t* pa = in.bytes + (REV ? in.base + (in.len - a - l) : in.base + a);
+    const uint8_t* pb = in.bytes + (REV ? in.base + (in.len - b - l) : in.base + b);
+    uint32_t k = 0;
+    for (; k + 8 <= l; k += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, pa + k, 8);
+        __builtin_memcpy(&y, pb + k, 8);
+        if (x != y) return false;
+    }
+    for (; k < l; k++)
+        if (pa[k] != pb[k]) return false;
+    return true;
+}
+
+// exclusive end (scan index) of the run of byte `c` that starts at scan index i
+template <bool REV>
+__device__ __forceinline__ uint32_t run_end_from(const Input& in, uint32_t i, uint32_t c) {
+    uint32_t j = i + 1;
+    while (j < in.len && in.bytes[scan_addr<REV>(in, j)] == c) j++;
+    return j;
+}
+
+// ---- the walk -----------------------------------------------------------------------------------
+template <int K, bool REV, bool LDS_SLOTS>
+struct Walker {
+    DevImg   g;
+    Slots<K, LDS_SLOTS> S;
+    Input    in;
+    uint32_t curbuf;         // wave-uniform
+    // per-lane
+    bool     active;         // has a string in flight
+    bool     accept;
+    bool     any_next;       // something was inserted into the next state set this step
+    uint32_t i;              // step index (scan position)
+    uint32_t ch;             // scan[i]
+    bool     final_pass;     // i == len
+    // cached run of equal bytes: scan[run_lo, run_hi) == run_ch, maximal to the right
+    uint32_t run_lo, run_hi, run_ch;
+
+    __device__ __forceinline__ void load_mem(uint32_t buf, uint32_t node, Mem<K>& m) const {
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            m.start[c] = *S.at(buf, node, 3 + 3 * c);
+            m.len[c]   = *S.at(buf, node, 4 + 3 * c);
+            m.fl[c]    = *S.at(buf, node, 5 + 3 * c);
+        }
+    }
+
+    // insert (P,Q,R,m) into the next-set slot of `node` if it beats what is there
+    __device__ __forceinline__ void insert(bool pred, uint32_t node, uint32_t P, uint32_t Q, uint32_t R, const Mem<K>& m) {
+        uint32_t nb = curbuf ^ 1u;
+        uint32_t eP = *S.at(nb, node, 0), eQ = *S.at(nb, node, 1), eR = *S.at(nb, node, 2);
+        bool win = pred && (P < eP || (P == eP && (Q < eQ || (Q == eQ && R < eR))));
+        if (win) {
+            *S.at(nb, node, 0) = P; *S.at(nb, node, 1) = Q; *S.at(nb, node, 2) = R;
+#pragma unroll
+            for (int c = 0; c < K; c++) {
+                *S.at(nb, node, 3 + 3 * c) = m.start[c];
+                *S.at(nb, node, 4 + 3 * c) = m.len[c];
+                *S.at(nb, node, 5 + 3 * c) = m.fl[c];
+            }
+            any_next = true;
+        }
+    }
+
+    // MFA::doMemoryWriteActions (mfa.cpp:80-105) on a copy; the consumed text is
+    // scan[tstart, tstart+tlen), all bytes equal `tch` iff tuni
+    __device__ __forceinline__ void apply_actions(Mem<K>& m, uint32_t actions, uint32_t tstart, uint32_t tlen,
+                                                  bool tuni, uint32_t tch) const {
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            uint32_t act = (actions >> (2 * (c + 1))) & 3u;       // wave-uniform
+            uint32_t f = m.fl[c];
+            if (act == MFA_ACT_OPEN) {                            // create if absent, open(), write(t)
+                m.start[c] = tstart; m.len[c] = tlen;
+                m.fl[c] = F_PRESENT | F_OPEN | (tuni ? F_UNI : 0u) | (tch << 8);
+            } else if (act == MFA_ACT_CLOSE) {                    // close()
+                m.fl[c] = f & ~F_OPEN;
+            } else {                                              // write(t) when open
+                bool w = (f & (F_PRESENT | F_OPEN)) == (F_PRESENT | F_OPEN) && tlen != 0u;
+                bool was_empty = m.len[c] == 0u;
+                uint32_t fch = (f >> 8) & 0xffu;
+                bool uni = was_empty ? tuni : ((f & F_UNI) && tuni && fch == tch);
+                uint32_t nf = (f & (F_PRESENT | F_OPEN | F_READ)) | (uni ? F_UNI : 0u) | ((was_empty ? tch : fch) << 8);
+                if (w) {
+                    if (was_empty) m.start[c] = tstart;
+                    m.len[c] += tlen;
+                    m.fl[c] = nf;
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ bool suffix_ok(bool pred, const Mem<K>& m) const {        // mfa.cpp:116-133
+        if (!REV) return pred;
+        uint32_t needed = 0;
+#pragma unroll
+        for (int c = 0; c < K; c++)
+            if ((m.fl[c] & F_PRESENT) && ((m.fl[c] & F_OPEN) || !(m.fl[c] & F_READ))) needed += m.len[c];
+        return pred && needed <= in.len - i;
+    }
+
+    // does scan[i, i+l) equal the value of cell (start,len=l,flags)?   (mfa.cpp:178-187)
+    __device__ __forceinline__ bool read_matches(uint32_t start, uint32_t l, uint32_t fl) {
+        if (in.len - i < l) return false;
+        if (l == 0u) return true;
+        if (fl & F_UNI) {                                  // value is one byte repeated: compare against the run at i
+            uint32_t c = (fl >> 8) & 0xffu;
+            if (c != ch) return false;
+            if (l == 1u) return true;
+            if (!(run_ch == c && run_lo <= i && i < run_hi)) {
+                run_hi = run_end_from<REV>(in, i, c);
+                run_lo = i; run_ch = c;
+            }
+            return run_hi - i >= l;
+        }
+        return spans_equal<REV>(in, start, i, l);
+    }
+
+    // MFA::evaluateState (mfa.cpp:136-200) for the lanes in `live`, all of which sit on `node`
+    // with state (pos, m).  LEVEL = recursion depth through "unset cell" edges (mfa.cpp:148-160).
+    template <int LEVEL>
+    __device__ __forceinline__ void eval_node(uint32_t node, bool live, uint32_t pos, Mem<K>& m, uint32_t Q, uint32_t Rprefix) {
+        live = suffix_ok(live, m);
+        if (!__any(live)) return;
+        const bool here    = live && !final_pass && pos == i;     // may consume (mfa.cpp:161)
+        const bool waiting = live && !final_pass && pos > i;      // mfa.cpp:195
+        bool reinsert = false;
+        const uint32_t e0 = g.edge_begin[node], e1 = g.edge_begin[node + 1];
+        for (uint32_t e = e0; e < e1; e++) {
+            const uint2 ed = g.edges[e];                           // uniform -> scalar load
+            const uint32_t label = ed.x & 0xffu, eflags = (ed.x >> 8) & 0xffu, target = ed.x >> 16, actions = ed.y;
+            const uint32_t R = Rprefix | ((e - e0 + 1u) << (5 * (K - LEVEL)));
+            if (eflags & MFA_EDGE_EPS) {                           // mfa.cpp:143-147 -> finish keeps it iff pos == len
+                if (live && pos == in.len) accept = true;
+                continue;
+            }
+            const bool is_digit = label >= '1' && label <= '9';
+            const int  d = is_digit ? (int)label - '1' : 0;       // 0-based cell, uniform
+            bool absent = false;
+            if (is_digit) {
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c == d) absent = !(m.fl[c] & F_PRESENT);
+            }
+            const bool take_absent = live && absent;
+            if constexpr (LEVEL < K) {
+                if (__any(take_absent)) {                          // mfa.cpp:148-160: create the cell, recurse, consume nothing
+                    Mem<K> t = m;
+                    uint32_t act = (actions >> (2 * (d + 1))) & 3u;
+#pragma unroll
+                    for (int c = 0; c < K; c++)
+                        if (c == d) {
+                            t.start[c] = pos; t.len[c] = 0u;
+                            t.fl[c] = F_PRESENT | (act == MFA_ACT_OPEN ? F_OPEN : 0u) | F_UNI;
+                        }
+                    eval_node<LEVEL + 1>(target, take_absent, pos, t, Q, R);
+                }
+            }
+            const bool other = live && !absent;
+            const bool consume = other && here;
+            const bool lit = consume && (label == '.' || label == ch);             // mfa.cpp:171
+            if (__any(lit)) {
+                Mem<K> t = m;
+                apply_actions(t, actions, i, 1u, true, ch);
+                insert(lit, target, ((pos + 1u) << 4) | first_name(t), Q, R, t);
+            }
+            const bool rd = consume && !lit && is_digit;                           // mfa.cpp:176
+            if (__any(rd)) {
+                Mem<K> t = m;                                     // copy BEFORE read() marks the source (mfa.cpp:167 vs 177)
+                uint32_t vs = 0, vl = 0, vf = 0;
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if (c == d) { vs = m.start[c]; vl = m.len[c]; vf = m.fl[c]; if (rd) m.fl[c] |= F_READ; }
+                bool ok = rd && read_matches(vs, vl, vf);
+                if (__any(ok)) {
+                    apply_actions(t, actions, i, vl, (vf & F_UNI) != 0u, (vf >> 8) & 0xffu);
+                    insert(ok, target, ((pos + vl) << 4) | first_name(t), Q, R, t);
+                }
+            }
+            reinsert = reinsert || (other && waiting);                             // mfa.cpp:195-197
+        }
+        if (__any(reinsert)) {
+            // the state itself goes back into the set; at LEVEL 0 it is the old object (older than
+            // anything created this step: Q = R = 0), deeper it is the state the unset-cell edge made
+            insert(reinsert, node, (pos << 4) | first_name(m), LEVEL == 0 ? 0u : Q, LEVEL == 0 ? 0u : Rprefix, m);
+        }
+    }
+
+    __device__ __forceinline__ void clear_lane_slots() {
+        for (uint32_t n = 0; n < g.n_nodes; n++) { *S.at(0, n, 0) = kEmpty; *S.at(1, n, 0) = kEmpty; }
+    }
+
+    __device__ __forceinline__ void start_string(uint64_t base, uint32_t len) {
+        in.base = base; in.len = len; in.blk = ~(uint64_t)0;
+        i = 0; accept = false; active = true;
+        run_lo = run_hi = 0; run_ch = 0x100u;
+        clear_lane_slots();
+        *S.at(curbuf, g.start, 0) = 0u;                            // (pos 0, start, {})  mfa.cpp:217-219
+#pragma unroll
+        for (int c = 0; c < K; c++) {
+            *S.at(curbuf, g.start, 3 + 3 * c) = 0u; *S.at(curbuf, g.start, 4 + 3 * c) = 0u; *S.at(curbuf, g.start, 5 + 3 * c) = 0u;
+        }
+    }
+
+    // one evaluateStates call (mfa.cpp:203-213) for every active lane; returns per lane
+    // whether the string is finished after it
+    __device__ __forceinline__ bool step() {
+        final_pass = (i == in.len);
+        ch = 0x100u;
+        if (active && !final_pass) ch = cached_byte(in, scan_addr<REV>(in, i));
+        any_next = false;
+        for (uint32_t n = 0; n < g.n_nodes; n++) {
+            uint32_t P = active ? *S.at(curbuf, n, 0) : kEmpty;
+            bool live = P != kEmpty;
+            if (!__any(live)) continue;
+            if (live) *S.at(curbuf, n, 0) = kEmpty;               // consumed: this buffer is the next step's empty set
+            uint32_t pos = P >> 4;
+            live = live && pos >= i;                               // pos < i: nothing can be inserted from a stale state
+            if (!__any(live)) continue;
+            Mem<K> m;
+            load_mem(curbuf, n, m);
+            eval_node<0>(n, live, pos, m, (pos << 8) | n, 0u);
+        }
+        bool done = false;
+        if (active) {
+            if (accept || final_pass || !any_next) done = true;    // mfa.cpp:224-225, 227-235
+            i++;
+        }
+        return done;
+    }
+};
+
+template <int K, bool REV, bool LDS_SLOTS>
+__global__ void __launch_bounds__(64)
+mfa_walk_kernel(DevImg g, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
+                uint8_t* __restrict__ results, unsigned long long* counter, uint32_t* scratch) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63u;
+    Walker<K, REV, LDS_SLOTS> w;
+    w.g = g;
+    w.S.N = g.n_nodes;
+    if (LDS_SLOTS) w.S.base = lds + lane;
+    else w.S.base = scratch + (size_t)blockIdx.x * (2u * g.n_nodes * SlotLayout<K>::W * 64u) + lane;
+    w.in.bytes = bytes;
+    w.curbuf = 0;
+    w.active = false; w.accept = false; w.i = 0; w.in.len = 0; w.in.base = 0; w.in.blk = ~(uint64_t)0;
+    w.run_lo = w.run_hi = 0; w.run_ch = 0x100u;
+    uint64_t sid = 0;
+    bool exhausted = false;
+    for (;;) {
+        // hand a new string to every idle lane
+        if (!w.active && !exhausted) {
+            for (;;) {
+                sid = atomicAdd(counter, 1ull);
+                if (sid >= n) { exhausted = true; break; }
+                uint64_t b = offsets[sid], e = offsets[sid + 1];
+                uint64_t len = e - b;
+                if (len > MFA_MAX_STRING_BYTES) { results[sid] = 2; continue; }    // flagged; the launcher reports it
+                w.start_string(b, (uint32_t)len);
+                break;
+            }
+        }
+        if (!__any(w.active)) break;
+        bool done = w.step();
+        if (done) {
+            results[sid] = w.accept ? 1 : 0;
+            w.active = false;
+        }
+        w.curbuf ^= 1u;
+    }
+}
+
+// ---- table walk for memory-less automata -------------------------------------------------------
+// One string per lane; the transition table ([state][class], 16-bit) and the byte-class map sit
+// in LDS.  State 0 is the empty set: absorbing and rejecting, the reference's early `break`
+// (automata.cpp:186-188,196-198).
+template <bool REV>
+__global__ void __launch_bounds__(256)
+dfa_walk_kernel(const uint16_t* __restrict__ trans, const uint8_t* __restrict__ accept_tab,
+                const uint8_t* __restrict__ byte_class, uint32_t n_states, uint32_t n_classes,
+                const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
+                uint8_t* __restrict__ results) {
+    extern __shared__ uint32_t lds[];
+    uint16_t* s_trans = reinterpret_cast<uint16_t*>(lds);
+    uint8_t*  s_cls   = reinterpret_cast<uint8_t*>(s_trans + ((n_states * n_classes + 1u) & ~1u));
+    for (uint32_t k = threadIdx.x; k < n_states * n_classes; k += blockDim.x) s_trans[k] = trans[k];
+    for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) s_cls[k] = byte_class[k];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t sid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sid < n; sid += stride) {
+        const uint64_t b = offsets[sid], e = offsets[sid + 1];
+        uint32_t st = 1u;
+        if (!REV) {
+            for (uint64_t p = b; p < e && st != 0u; p++) st = s_trans[st * n_classes + s_cls[bytes[p]]];
+        } else {
+            for (uint64_t p = e; p > b && st != 0u; p--) st = s_trans[st * n_classes + s_cls[bytes[p - 1]]];
+        }
+        results[sid] = accept_tab[st];
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------
+template <int K, bool REV>
+static int launch_mfa_k(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                        uint64_t n, uint8_t* d_results, hipStream_t stream) {
+    DevImg g{ds.d_edge_begin, ds.d_edges, img.h.n_nodes, img.h.start, img.h.finish, img.h.is_reversed};
+    const size_t per_wave = (size_t)2 * img.h.n_nodes * SlotLayout<K>::W * 64 * sizeof(uint32_t);
+    const bool lds_slots = per_wave <= 40 * 1024;             // >= 4 waves per CU out of 160 KiB
+    HIP_TRY(hipMemsetAsync(ds.d_counter, 0, sizeof(unsigned long long), stream));
+    int waves_per_cu = 8;
+    if (lds_slots) {
+        int by_lds = (int)((160 * 1024) / per_wave);
+        if (by_lds < waves_per_cu) waves_per_cu = by_lds;
+    }
+    uint64_t want = (n + 63) / 64;
+    uint64_t grid = (uint64_t)ds.n_cus * waves_per_cu;
+    if (grid > want) grid = want;
+    if (grid == 0) grid = 1;
+    if (!lds_slots) {
+        size_t need = (size_t)grid * per_wave;
+        if (need > ds.scratch_bytes) {
+            if (ds.d_scratch) HIP_TRY(hipFree(ds.d_scratch));
+            ds.d_scratch = nullptr; ds.scratch_bytes = 0;
+            HIP_TRY(hipMalloc(&ds.d_scratch, need));
+            ds.scratch_bytes = need;
+        }
+    }
+    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_start, stream));
+    if (lds_slots) {
+        auto kern = mfa_walk_kernel<K, REV, true>;
+        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave));
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), per_wave, stream, g, d_bytes, d_offsets, n, d_results,
+                           ds.d_counter, (uint32_t*)nullptr);
+    } else {
+        hipLaunchKernelGGL((mfa_walk_kernel<K, REV, false>), dim3((unsigned)grid), dim3(64), 0, stream, g, d_bytes,
+                           d_offsets, n, d_results, ds.d_counter, ds.d_scratch);
+    }
+    HIP_TRY(hipGetLastError());
+    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_stop, stream));
+    return MFA_OK;
+}
+
+template <int K>
+static int launch_mfa_rev(const HostImage& img, DeviceState& ds, const uint8_t* b, const uint64_t* o, uint64_t n,
+                          uint8_t* r, hipStream_t s) {
+    return img.h.is_reversed ? launch_mfa_k<K, true>(img, ds, b, o, n, r, s) : launch_mfa_k<K, false>(img, ds, b, o, n, r, s);
+}
+
+int launch_mfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                    uint64_t n, uint8_t* d_results, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    switch (img.h.n_cells) {
+        case 0:
+        case 1: return launch_mfa_rev<1>(img, ds, d_bytes, d_offsets, n, d_results, s);
+        case 2: return launch_mfa_rev<2>(img, ds, d_bytes, d_offsets, n, d_results, s);
+        case 3: return launch_mfa_rev<3>(img, ds, d_bytes, d_offsets, n, d_results, s);
+        case 4: return launch_mfa_rev<4>(img, ds, d_bytes, d_offsets, n, d_results, s);
+    }
+    return MFA_ERR_UNSUPPORTED;
+}
+
+int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                    uint64_t n, uint8_t* d_results, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    size_t tab = ((size_t)img.dfa_states * img.n_classes + 1) & ~(size_t)1;
+    size_t lds = tab * sizeof(uint16_t) + 256;
+    if (lds > 160 * 1024) return MFA_ERR_UNSUPPORTED;
+    uint64_t blocks = (n + 255) / 256;
+    uint64_t cap = (uint64_t)ds.n_cus * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_start, s));
+    if (img.h.is_reversed) {
+        HIP_TRY(hipFuncSetAttribute((const void*)dfa_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(dfa_walk_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, ds.d_dfa_trans, ds.d_dfa_accept,
+                           ds.d_byte_class, img.dfa_states, img.n_classes, d_bytes, d_offsets, n, d_results);
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void*)dfa_walk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(dfa_walk_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, ds.d_dfa_trans, ds.d_dfa_accept,
+                           ds.d_byte_class, img.dfa_states, img.n_classes, d_bytes, d_offsets, n, d_results);
+    }
+    HIP_TRY(hipGetLastError());
+    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_stop, s));
+    return MFA_OK;
+}
+
+}  // namespace mfa

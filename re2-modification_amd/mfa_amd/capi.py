@@ -1,0 +1,134 @@
+"""ctypes binding of libmfa_hip.so (include/mfa_hip.h).
+
+Thin by design: the product is the C-ABI library; Python is used by the tests and the
+bench to allocate device memory (torch) and to launch ranks (torch.distributed).
+There is no fallback: if the library is missing, loading raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmfa_hip.so")
+
+OK = 0
+ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_TOO_LONG = -1, -2, -3, -4, -5, -6, -7
+
+EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_match_batch",
+           "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_device_count", "mfa_last_hip_error", "mfa_strerror",
+           "mfa_version"]
+
+
+class MfaError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        msg = lib().mfa_strerror(code).decode()
+        if code == ERR_HIP:
+            msg += " (hipError %d)" % lib().mfa_last_hip_error()
+        super().__init__("%s: %s [%d]" % (where, msg, code))
+
+
+class ImageInfo(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in
+                ("kind", "is_reversed", "n_nodes", "n_edges", "n_cells", "dfa_states", "byte_classes", "reserved")]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libmfa_hip.so is not built (run python -c 'import __graft_entry__ as g; g.build()'): "
+                              + LIB_PATH)
+        # A process must hold ONE HIP runtime.  torch bundles its own libamdhip64 (same soname as
+        # /opt/rocm's): load torch first so the dynamic loader resolves our NEEDED entry to the copy
+        # torch already mapped instead of mapping a second runtime that cannot see the device.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = ctypes.CDLL(LIB_PATH)
+        vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
+        L.mfa_image_create.argtypes = [vp, ctypes.c_size_t, ctypes.POINTER(vp)]
+        L.mfa_image_create.restype = i32
+        L.mfa_image_destroy.argtypes = [vp]
+        L.mfa_image_destroy.restype = None
+        L.mfa_image_get_info.argtypes = [vp, ctypes.POINTER(ImageInfo)]
+        L.mfa_image_prepare.argtypes = [vp, i32]
+        L.mfa_match_batch.argtypes = [vp, vp, vp, u64, vp, i32, vp]
+        L.mfa_match_batch_host.argtypes = [vp, vp, vp, u64, vp, i32]
+        L.mfa_last_kernel_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
+        L.mfa_strerror.argtypes = [i32]
+        L.mfa_strerror.restype = ctypes.c_char_p
+        L.mfa_version.restype = ctypes.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, where):
+    if rc != OK:
+        raise MfaError(rc, where)
+
+
+class Image:
+    """An automaton image handle (mfa_image_t*)."""
+
+    def __init__(self, blob):
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(bytes(blob), len(blob))
+        _check(lib().mfa_image_create(buf, len(blob), ctypes.byref(self._h)), "mfa_image_create")
+
+    def info(self):
+        out = ImageInfo()
+        _check(lib().mfa_image_get_info(self._h, ctypes.byref(out)), "mfa_image_get_info")
+        return {n: getattr(out, n) for n, _ in ImageInfo._fields_}
+
+    def prepare(self, device=0):
+        _check(lib().mfa_image_prepare(self._h, device), "mfa_image_prepare")
+
+    def match_device(self, d_bytes_ptr, d_offsets_ptr, n, d_results_ptr, device=0, stream=0):
+        """Raw device pointers (ints); asynchronous on `stream` (a hipStream_t value, 0 = default)."""
+        _check(lib().mfa_match_batch(self._h, d_bytes_ptr, d_offsets_ptr, n, d_results_ptr, device,
+                                     ctypes.c_void_p(stream)), "mfa_match_batch")
+
+    def match_tensors(self, d_bytes, d_offsets, d_results=None, stream=None):
+        """torch CUDA tensors: uint8 bytes, int64 offsets (n+1) -> uint8 results (n).  Enqueued on
+        `stream` (torch stream; default: the current one)."""
+        import torch
+        n = d_offsets.numel() - 1
+        dev = d_offsets.device.index or 0
+        if d_results is None:
+            d_results = torch.empty(max(n, 1), dtype=torch.uint8, device=d_offsets.device)
+        s = stream if stream is not None else torch.cuda.current_stream(d_offsets.device)
+        self.match_device(d_bytes.data_ptr(), d_offsets.data_ptr(), n, d_results.data_ptr(), dev, s.cuda_stream)
+        return d_results[:n]
+
+    def match_host(self, data, offsets, device=0):
+        """numpy uint8 data + uint64 offsets(n+1) in host memory -> numpy uint8 results."""
+        import numpy as np
+        n = len(offsets) - 1
+        res = np.zeros(max(n, 1), dtype=np.uint8)
+        _check(lib().mfa_match_batch_host(self._h, data.ctypes.data, offsets.ctypes.data, n, res.ctypes.data, device),
+               "mfa_match_batch_host")
+        return res[:n]
+
+    def last_kernel_ms(self, device=0):
+        ms = ctypes.c_float()
+        _check(lib().mfa_last_kernel_ms(self._h, device, ctypes.byref(ms)), "mfa_last_kernel_ms")
+        return ms.value
+
+    def close(self):
+        if self._h:
+            lib().mfa_image_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def device_count():
+    return lib().mfa_device_count()
