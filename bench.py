@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Benchmark of the match path: input GB/s on the 10-example attack corpus (BASELINE.json metric).
+
+One step = one pass of the hot path over this rank's shard of the corpus: for each of the ten README
+examples (plain-mode MFA, as `./diploma -match` compiles them) one `mfa_match_batch` launch over that
+example's strings, then the result bitmap of the shard is gathered to rank 0 (RCCL when N > 1).
+Per-GPU work is fixed (weak scaling): rank r holds `--strings-per-example` strings of every example,
+`prefix + pumped_string(n, pump) [+ suffix]` with n log-uniform in [--min-len, --max-len]
+(generator: reference matchers/example_runner.cpp:15-29), generated on the device before the timed
+region, so the timed region starts with all inputs resident in HBM.
+
+Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+                 --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "re2-modification_amd"))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from mfa_amd import capi, corpus, image  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def load_blob(name):
+    with open(os.path.join(GOLDEN, "images", name + ".dump")) as f:
+        return image.blob_from_dump(f.read())
+
+
+def cpu_baseline(shards, budget_strings=3):
+    """Time the reference itself (oracle/_ref/ref_harness: its own sources, built as it builds them, no
+    -O flag, canonical allocation-order mode) on a bounded sample of the same workload; falls back to
+    our CPU restatement when the reference build is not present."""
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    cli = os.path.join(ROOT, "oracle", "oracle_cli")
+    use_ref = os.path.exists(ref)
+    if not use_ref and not os.path.exists(cli):
+        return None
+    tot_bytes, tot_sec, n_str = 0, 0.0, 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for ex, sh in shards.items():
+            # the shortest-but-representative sample: first strings of the shard, capped in length so the
+            # whole baseline stays within ~10-30 s (the reference is ~quadratic in string length)
+            sample = [s for s in sh["sample"] if len(s) <= 16384][:budget_strings]
+            if not sample:
+                continue
+            text = b"".join(s + b"\n" for s in sample)
+            if use_ref:
+                cmd = [ref, "time", "plain", corpus.EXAMPLES[ex][0]]
+            else:
+                blob_path = os.path.join(tmp, "ex%d.blob" % ex)
+                with open(blob_path, "wb") as f:
+                    f.write(sh["blob"])
+                cmd = [cli, "time", blob_path]
+            p = subprocess.run(cmd, input=text, capture_output=True, cwd=tmp)
+            if p.returncode != 0:
+                return None
+            f = p.stdout.split()
+            n_str += int(f[0]); tot_bytes += int(f[1]); tot_sec += float(f[2])
+    if tot_sec <= 0:
+        return None
+    return {"value": tot_bytes / tot_sec / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference" if use_ref else "port",
+            "sample": "%d strings (first <=%d of each example's shard with length <= 16 KiB), %d bytes, %.1f s, 1 thread" % (
+                n_str, budget_strings, tot_bytes, tot_sec)}
+
+
+def secondary_dfa(device, n_strings=1 << 20, length=1024):
+    """BASELINE.json configs[1]: Thompson automaton of (a|b)*abb through the API, 1M random 1 KiB strings."""
+    img = capi.Image(load_blob("nfa_abb_thompson"))
+    g = torch.Generator(device=device); g.manual_seed(0x5EED0002)
+    data = torch.randint(0, 2, (n_strings, length), generator=g, device=device, dtype=torch.uint8) + ord("a")
+    data[0::2, -3:] = torch.tensor(list(b"abb"), dtype=torch.uint8, device=device)
+    flat = torch.cat([data.reshape(-1), torch.zeros(64, dtype=torch.uint8, device=device)])
+    off = torch.arange(0, (n_strings + 1) * length, length, dtype=torch.int64, device=device)
+    res = torch.empty(n_strings, dtype=torch.uint8, device=device)
+    ms = []
+    for _ in range(4):
+        img.match_tensors(flat, off, res)
+        ms.append(img.last_kernel_ms(device.index or 0))
+    torch.cuda.synchronize()
+    t = float(np.mean(ms[1:]))
+    want = (data[:, -3] == ord("a")) & (data[:, -2] == ord("b")) & (data[:, -1] == ord("b"))
+    ok = bool(torch.equal(res.bool(), want))
+    gbs = n_strings * length / (t * 1e-3) / 1e9
+    return {"workload": "(a|b)*abb Thompson NFA (tabulated), %d random %d-byte strings" % (n_strings, length),
+            "kernel": "dfa_walk_kernel", "kernel_ms": t, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+            "results_exact": ok}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--strings-per-example", type=int, default=125000,
+                    help="strings of each example per GPU (125000 x 10 examples x 8 GPUs = the 10M-string batch)")
+    ap.add_argument("--min-len", type=int, default=1024)
+    ap.add_argument("--max-len", type=int, default=65536)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    # ---- this rank's shard, resident in HBM ---------------------------------------------------------
+    shards = {}
+    n_per = args.strings_per_example
+    total_bytes, total_strings = 0, 0
+    for ex in sorted(corpus.EXAMPLES):
+        seed = 0x5EED0004 + 1000 * rank + ex
+        sizes = corpus.pump_sizes(n_per, seed, args.min_len, args.max_len)
+        with_suffix = (np.arange(n_per) % 2) == 0
+        d_bytes, d_off = corpus.device_batch(ex, sizes, with_suffix, device)
+        blob = load_blob("ex%d_plain" % ex)
+        img = capi.Image(blob)
+        img.prepare(local)
+        nbytes = int(d_off[-1].item())
+        shards[ex] = {"img": img, "bytes": d_bytes, "off": d_off, "n": n_per, "nbytes": nbytes, "blob": blob,
+                      "sample": corpus.host_strings(ex, sizes[:16], with_suffix[:16]) if rank == 0 else []}
+        total_bytes += nbytes
+        total_strings += n_per
+    results = torch.zeros(total_strings, dtype=torch.uint8, device=device)
+    bit_w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=device)
+    n_bitmap = (total_strings + 7) // 8
+    gathered = [torch.empty(n_bitmap, dtype=torch.uint8, device=device) for _ in range(world)] if (dist and rank == 0) else None
+    kernel_ms = {ex: [] for ex in shards}
+
+    def step(record):
+        pos = 0
+        for ex, sh in shards.items():
+            sh["img"].match_tensors(sh["bytes"], sh["off"], results[pos:pos + sh["n"]])
+            pos += sh["n"]
+        pad = (-total_strings) % 8
+        r = torch.cat([results, results.new_zeros(pad)]) if pad else results
+        bitmap = (r.view(-1, 8) * bit_w).sum(dim=1, dtype=torch.uint8)
+        if dist:
+            dist.gather(bitmap, gathered, dst=0)      # RCCL over xGMI: the path's only exchange
+        if record:
+            for ex, sh in shards.items():
+                kernel_ms[ex].append(sh["img"].last_kernel_ms(local))
+        return bitmap
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_bytes * world * args.steps / dt / 1e9
+        # roofline of the dominant kernel (mfa_walk_kernel): algorithmic bytes of one step's launches
+        # (1 B per input character + 8 B offset + 1 B result per string) over their summed durations
+        alg = total_bytes + 9 * total_strings
+        kern_s = sum(float(np.mean(v)) for v in kernel_ms.values()) * 1e-3
+        achieved = alg / kern_s / 1e9
+        per_ex = {str(ex): {"kernel_ms": float(np.mean(kernel_ms[ex])), "bytes": shards[ex]["nbytes"],
+                            "GB/s": shards[ex]["nbytes"] / (float(np.mean(kernel_ms[ex])) * 1e-3) / 1e9,
+                            "accepted": None} for ex in shards}
+        pos = 0
+        for ex, sh in shards.items():
+            per_ex[str(ex)]["accepted"] = int(results[pos:pos + sh["n"]].sum().item())
+            pos += sh["n"]
+        out = {
+            "metric": "input GB/s (chars matched/sec) on 10-example attack corpus",
+            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "10 README MFA examples (plain mode), %d pumped attack strings per example per GPU, "
+                                   "pump size log-uniform [%d, %d], alternating with/without suffix "
+                                   "(BASELINE configs[3] shard: 10M strings over 8 GPUs)" % (n_per, args.min_len, args.max_len),
+                       "strings_per_gpu": total_strings, "bytes_per_gpu": total_bytes, "parallelism": "dp%d" % world,
+                       "exchange": "gather of the result bitmap to rank 0" + (" (RCCL)" if dist else " (single rank: none)")},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mfa_walk_kernel (10 launches per step, one per example)",
+                         "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s},
+            "per_example": per_ex,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(shards)
+        if not args.no_secondary and world == 1:
+            out["secondary"] = [secondary_dfa(device)]
+        print(json.dumps(out))
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
