@@ -1,0 +1,254 @@
+// Host-side mirror of the reference's C++ API for the match path, backed by the MI355X
+// kernels through the C-ABI of include/mfa_hip.h.
+//
+// Same class names, public fields and call signatures as the reference, so code written
+// against it (matchers/match.cpp:10-32, matchers/match_mfa.cpp:13-97,
+// matchers/example_runner.cpp:106-111) compiles against this header unchanged:
+//
+//   reference                              here
+//   ---------------------------------------------------------------------------------------
+//   variable.h:8-41    Variable            Variable            (kept for source parity; the
+//                                                               kernels hold cells as spans)
+//   edge.h:13-49       Edge, MemoryEdge,   same                + `seq`
+//                      MemoryAction
+//   node.h:11-38       Node, MemoryNode    same                + `seq`
+//   automata.h:18-84   Automata, MFA       same                match() runs on the GPU;
+//                                                              + match_batch(), image_blob()
+//   bt/binary_tree.h   BinaryTree          same                toThomson/toGlushkov/toMFA
+//   regex/regex.h      Regexp, RegexpType  same                parse_regexp/to_binary_tree/
+//                                                              compile/reverse (memory-less)
+//
+// What is different, and why:
+//  * `seq`: the reference orders nodes, edges and states by raw heap pointers
+//    (automata.h:12-13, bt/bt_mfa.cpp:51,87,91,122-128, bt/bt_thomson.cpp:26-27).  Under the
+//    canonical allocation-order model a pointer comparison is an
+//    allocation-sequence comparison; every graph object here carries the sequence number the
+//    reference's allocation would have had, and every place the reference compares pointers
+//    compares `seq` instead.  Results are then independent of the host heap.
+//  * match() does not walk the graph on the CPU.  The graph is frozen into an automaton
+//    image (include/mfa_image_format.h) and handed to libmfa_hip.so; there is no CPU fallback:
+//    without a usable GPU match() throws std::runtime_error.
+//  * The BNF rewriter (regex/bnf.cpp, helpers.cpp) and reversal of memory regexes
+//    (regex/reverse.cpp:59-113) are not part of this round; compile()
+//    with use_bnf / use_reverse on a regex with memory throws std::runtime_error saying so.
+#ifndef DIPLOMA_API_H
+#define DIPLOMA_API_H
+
+#include <cstdint>
+#include <list>
+#include <map>
+#include <set>
+#include <string>
+#include <utility>
+#include <vector>
+
+using namespace std;   // the reference's headers do this (automata.h:15, node.h:9, edge.h:8)
+
+struct mfa_image;      // include/mfa_hip.h
+
+namespace diploma {
+uint64_t next_seq();   // allocation sequence number (monotonic, process-wide)
+}
+
+// ---- variable.h -----------------------------------------------------------------------------------
+class Variable {
+public:
+    bool is_open = false;
+    bool is_read = false;
+    string value;
+    Variable() = default;
+    Variable(bool open_, string v, bool read_ = false) : is_open(open_), is_read(read_), value(std::move(v)) {}
+    void open() { is_open = true; is_read = false; value.clear(); }
+    void close() { is_open = false; }
+    string& read() { is_read = true; return value; }
+    void write(const string& a) { value += a; }
+};
+
+// ---- edge.h / node.h --------------------------------------------------------------------------------
+class Node;
+class MemoryNode;
+
+class Edge {
+public:
+    string by;
+    Node* to = nullptr;
+    bool drawn = false;
+    uint64_t seq = diploma::next_seq();
+    Edge() = default;
+    Edge(string label, Node* target) : by(std::move(label)), to(target) {}
+};
+
+enum MemoryAction { open, close };
+
+class MemoryEdge : public Edge {
+public:
+    map<string, MemoryAction> memoryActions;
+    MemoryNode* to = nullptr;
+    MemoryEdge() = default;
+    MemoryEdge(string label, MemoryNode* target) : to(target) { by = std::move(label); }
+    void addAction(const string& var, MemoryAction action) { memoryActions[var] = action; }
+};
+
+class Node {
+public:
+    list<Edge*> edges;
+    string name;
+    Node* finish_for = nullptr;
+    Node* start_for = nullptr;
+    uint64_t seq = diploma::next_seq();
+    Node() = default;
+    explicit Node(string n) : name(std::move(n)) {}
+};
+
+class MemoryNode {
+public:
+    list<MemoryEdge*> edges;
+    string name;
+    uint64_t seq = diploma::next_seq();
+    MemoryNode() = default;
+    explicit MemoryNode(string n) : name(std::move(n)) {}
+};
+
+// ---- automata.h ---------------------------------------------------------------------------------------
+#define Memory map<string, Variable*>
+#define MemoryState pair<int, pair<MemoryNode*, Memory>>
+
+class Automata {
+public:
+    Node* start;
+    Node* finish;
+    int last_idx;
+    list<Node*> nodes;
+    bool is_reversed = false;
+
+    Automata();
+    virtual ~Automata();
+
+    void makeDOTFile(const string& filename);
+    bool draw(const string& filename);
+    void changeFinalState(Node* new_final);
+    bool isDeterministic();
+
+    // reference automata.cpp:177-210, on the GPU (a batch of one)
+    bool match(const string& str);
+    // the same for many strings in one launch; result[k] is what match(strs[k]) returns
+    vector<bool> match_batch(const vector<string>& strs);
+    // packed form: string k is bytes[offsets[k], offsets[k+1]); results gets n bytes of 0/1
+    void match_packed(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* results);
+
+    // the automaton image handed to the device (include/mfa_image_format.h)
+    virtual vector<uint8_t> image_blob() const;
+    int device = 0;    // HIP device the match calls run on
+
+protected:
+    mfa_image* image_for_match();
+    mfa_image* cached_image_ = nullptr;
+    vector<uint8_t> cached_blob_;
+};
+
+class MFA : public Automata {
+public:
+    MemoryNode* start;
+    MemoryNode* finish;
+    list<MemoryNode*> nodes;
+    bool is_reversed = false;
+
+    MFA();
+
+    void changeFinalState(MemoryNode* new_final);
+    void makeDOTFile(const string& filename);
+    bool draw(const string& filename);
+
+    // reference mfa.cpp:215-236, on the GPU.  Non-virtual like the reference's: callers that hold an
+    // Automata* static_cast to MFA* when compile() set is_mfa (matchers/match.cpp:16-19).
+    bool match(string str);
+    vector<bool> match_batch(const vector<string>& strs);
+    void match_packed(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* results);
+
+    vector<uint8_t> image_blob() const override;
+};
+
+// ---- regex/regex.h ---------------------------------------------------------------------------------------
+class BinaryTree;
+
+enum RegexpType {
+    leftParenthesis, rightParenthesis, leftBrace, rightBrace, leftSquareBr, rightSquareBr, dash,
+    kleeneStar, kleenePlus, alternation, literal, epsilon,
+    alternationExpr, concatenationExpr, backreferenceExpr, reference, rootExpr
+};
+
+class Regexp {
+public:
+    RegexpType regexp_type = rootExpr;
+    string regexp_str;
+    char rune = 0;                    // literal
+    Regexp* sub_regexp = nullptr;     // kleene, backreference body
+    list<Regexp*> sub_regexps;        // alternation, concatenation
+    string variable;                  // backreference / reference name
+    bool is_read = false;
+    Regexp* reference_to = nullptr;
+    bool have_backreference = false;
+    bool is_one_unamb = false;
+    bool is_bad_bnf = false;
+
+    set<string> maybe_initialized;    // cells some path may initialise
+    set<string> maybe_read;           // cells some path may read
+
+    Regexp() = default;
+    explicit Regexp(RegexpType t) : regexp_type(t) {}
+
+    static Regexp* parse_regexp(string& s);           // consumes s, like the reference (parser.cpp:8)
+    string to_string();
+    bool is_backref_correct();
+    BinaryTree* to_binary_tree();
+    Regexp* reverse();                                // memory-less regexes only in this round
+    Regexp* bnf(bool is_log = false);                 // not in this round: throws
+    Automata* compile(bool& is_mfa, bool use_reverse, bool use_bnf, bool use_ssnf, bool use_log = false);
+
+private:
+    void close_alternative();                         // '|'
+    void close_group();                               // ')'
+    void wrap_kleene(char c);
+    void close_backreference(string name);
+    void close_enumeration();
+    void collect_memory_use();
+    Regexp* mirrored();
+};
+
+// ---- bt/binary_tree.h ---------------------------------------------------------------------------------
+class BinaryTree {
+public:
+    BinaryTree() {}
+    explicit BinaryTree(RegexpType t) : type(t) {}
+
+    RegexpType type = epsilon;
+    BinaryTree* left = nullptr;     // concatenation and alternation
+    BinaryTree* right = nullptr;
+    BinaryTree* child = nullptr;    // Kleene, backreference body
+    char rune = 0;                  // literal
+    string variable;                // reference and backreferenceExpr
+    string name;
+
+    bool epsilonProducing();
+    list<string> linearize(int&);
+    list<string> doFIRST();
+    list<string> doLAST();
+    set<pair<string, string>> doFOLLOW();
+    bool is_one_unambiguity();
+
+    Automata* toThomson();
+    Automata* toGlushkov();
+    MFA* toMFA();
+};
+
+std::string substr(std::string originalString, int maxLength);
+
+// matchers/match.cpp:10 -- the `-match` loop: compile once, then 0/1 per whitespace-separated token of
+// stdin until the token `exit` (or end of input), batched onto the GPU
+void match(string regexp_str, bool reverse, bool bnf, bool ssnf, bool use_log = false);
+// matchers/match_mfa.cpp:13,58 counterparts: strings from a file (one per line), one batch, results and
+// timing on stdout
+void match_gt(string regexp_str, const string& input_path = "input_strings.txt");
+void match_mfa(string regexp_str, const string& input_path = "mfa_str.txt");
+
+#endif  // DIPLOMA_API_H

@@ -44,3 +44,23 @@ def test_host_entry_point():
     img = capi.Image(image.blob_from_dump(oracle_lib.load_dump("ex1_plain")))
     data, off = oracle_lib.pack([b"aa", b"aaa", b"aaaa", b"b", b"aaaaaab", b"ab", b"aaaaaaaa", b""])
     assert list(img.match_host(data, off)) == [1, 1, 1, 0, 0, 0, 1, 1]
+
+
+def test_cli_match_contract(tmp_path):
+    """`./diploma -match`: header lines, then one 0/1 line per token, byte-identical with the reference
+    (main.cpp:42-44, matchers/match.cpp:21-31)."""
+    import subprocess
+    diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
+    for name in ("ex1_plain", "ex5_plain", "nfa_abb_plain", "nfa_third_plain"):
+        auto = next(a for a in MANIFEST["automata"] if a["name"] == name)
+        strings, want = [], []
+        for sset in auto["sets"]:
+            bits = oracle_lib.load_bits(name, sset)
+            for s, b in zip(oracle_lib.load_set(sset), bits):
+                if s:                              # the empty string cannot be a token of `cin >> text`
+                    strings.append(s); want.append(b)
+        text = auto["regex"].encode() + b"\n" + b"\n".join(strings) + b"\nexit\nnot-read\n"
+        p = subprocess.run([diploma, "-match"], input=text, capture_output=True, cwd=tmp_path)
+        assert p.returncode == 0, p.stderr
+        expect = auto["header"].encode() + b"".join(b"%d\n" % b for b in want)
+        assert p.stdout == expect, name
