@@ -41,6 +41,7 @@ extern "C" {
 #define MFA_ERR_HIP           -5  /* a HIP runtime call failed; mfa_last_hip_error() has the code       */
 #define MFA_ERR_NOMEM         -6
 #define MFA_ERR_TOO_LONG      -7  /* a string is longer than MFA_MAX_STRING_BYTES                       */
+#define MFA_ERR_JIT           -8  /* compiling a specialised kernel failed (the generic kernel still works) */
 
 /* limits of the device kernels (violations -> MFA_ERR_UNSUPPORTED at image creation) */
 #define MFA_MAX_NODES        128u      /* MFA kind: nodes                                  */
@@ -57,8 +58,13 @@ typedef struct mfa_image_info {
     uint32_t n_nodes, n_edges, n_cells;
     uint32_t dfa_states;   /* NFA kind: number of tabulated state sets (incl. the dead set) */
     uint32_t byte_classes; /* NFA kind: number of input byte classes                        */
-    uint32_t reserved;
+    uint32_t last_kernel;  /* MFA_KERNEL_*: which kernel the last match call on this image launched */
 } mfa_image_info;
+
+#define MFA_KERNEL_NONE        0u
+#define MFA_KERNEL_GENERIC     1u /* mfa_walk_kernel: table-driven memory-automaton walk, slots in LDS  */
+#define MFA_KERNEL_SPECIALISED 2u /* mfa_jit_kernel: the same walk generated for one automaton, slots in VGPRs */
+#define MFA_KERNEL_TABLE       3u /* dfa_walk_kernel: tabulated memory-less automaton                    */
 
 /* Build an image from a blob (include/mfa_image_format.h).  Host-only work: parse,
  * check the structural invariants the kernels rely on, and for MFA_KIND_NFA tabulate
@@ -71,6 +77,14 @@ int  mfa_image_get_info(const mfa_image_t* img, mfa_image_info* out);
 /* Upload the image's tables to `device` and allocate its launch workspace now
  * (otherwise done by the first match call on that device). */
 int  mfa_image_prepare(mfa_image_t* img, int device);
+
+/* Memory automata whose per-string state fits the register file get a kernel specialised to the
+ * automaton (straight-line code, no table loads): generated as HIP source, compiled for gfx950 with
+ * hipcc and cached as a code object next to the library (or in $MFA_JIT_CACHE).  This call does
+ * the generation and compilation now; it is host-only work and needs no GPU, so caches can be built
+ * ahead of time.  MFA_ERR_UNSUPPORTED: the automaton is too large (the generic kernel is used);
+ * MFA_ERR_JIT: the compiler failed.  Setting MFA_JIT=0 disables specialised kernels. */
+int  mfa_image_specialize(mfa_image_t* img);
 
 /* Match n strings; string k is bytes[offsets[k] .. offsets[k+1]).  ALL pointers are
  * DEVICE pointers on `device` (offsets has n+1 entries; results gets n bytes, 1 =

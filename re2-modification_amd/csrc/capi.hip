@@ -1,6 +1,7 @@
 // C-ABI of libmfa_hip.so (include/mfa_hip.h): glue between plain-C callers and the kernels.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 #include <new>
 
@@ -29,6 +30,7 @@ void device_release(DeviceState& ds) {
     if (ds.d_byte_class) (void)hipFree(ds.d_byte_class);
     if (ds.d_counter) (void)hipFree(ds.d_counter);
     if (ds.d_scratch) (void)hipFree(ds.d_scratch);
+    jit_unload(ds);
     if (ds.ev_start) (void)hipEventDestroy((hipEvent_t)ds.ev_start);
     if (ds.ev_stop) (void)hipEventDestroy((hipEvent_t)ds.ev_stop);
     ds = DeviceState{};
@@ -105,6 +107,7 @@ int mfa_image_get_info(const mfa_image_t* img, mfa_image_info* out) {
     out->kind = img->host.h.kind; out->is_reversed = img->host.h.is_reversed;
     out->n_nodes = img->host.h.n_nodes; out->n_edges = img->host.h.n_edges; out->n_cells = img->host.h.n_cells;
     out->dfa_states = img->host.dfa_states; out->byte_classes = img->host.n_classes;
+    out->last_kernel = img->last_kernel;
     return MFA_OK;
 }
 
@@ -112,7 +115,20 @@ int mfa_image_prepare(mfa_image_t* img, int device) {
     if (!img) return MFA_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(img->mu);
     DeviceState* ds = nullptr;
-    return device_prepare(img, device, &ds);
+    int rc = device_prepare(img, device, &ds);
+    if (rc == MFA_OK && img->host.h.kind == MFA_KIND_MFA) (void)jit_load(img->host, *ds);
+    return rc;
+}
+
+int mfa_image_specialize(mfa_image_t* img) {
+    if (!img) return MFA_ERR_INVALID_ARG;
+    if (!jit_enabled(img->host)) return MFA_ERR_UNSUPPORTED;
+    std::string err;
+    if (jit_compile(img->host, &err).empty()) {
+        fprintf(stderr, "mfa_hip: %s\n", err.c_str());
+        return MFA_ERR_JIT;
+    }
+    return MFA_OK;
 }
 
 int mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
@@ -124,7 +140,15 @@ int mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_
     int rc = device_prepare(img, device, &ds);
     if (rc != MFA_OK) return rc;
     HIP_TRY(hipSetDevice(device));
-    if (img->host.h.kind == MFA_KIND_MFA) return launch_mfa_walk(img->host, *ds, d_bytes, d_offsets, n, d_results, stream);
+    if (img->host.h.kind == MFA_KIND_MFA) {
+        if (jit_load(img->host, *ds)) {
+            img->last_kernel = MFA_KERNEL_SPECIALISED;
+            return launch_mfa_jit(*ds, d_bytes, d_offsets, n, d_results, stream);
+        }
+        img->last_kernel = MFA_KERNEL_GENERIC;
+        return launch_mfa_walk(img->host, *ds, d_bytes, d_offsets, n, d_results, stream);
+    }
+    img->last_kernel = MFA_KERNEL_TABLE;
     return launch_dfa_walk(img->host, *ds, d_bytes, d_offsets, n, d_results, stream);
 }
 
@@ -199,6 +223,7 @@ const char* mfa_strerror(int code) {
         case MFA_ERR_HIP: return "HIP runtime error";
         case MFA_ERR_NOMEM: return "out of host memory";
         case MFA_ERR_TOO_LONG: return "string longer than MFA_MAX_STRING_BYTES";
+        case MFA_ERR_JIT: return "compiling the specialised kernel failed";
     }
     return "unknown error";
 }

@@ -1,0 +1,147 @@
+// Specialised kernels: source from jit_gen.cpp, compiled for gfx950 with hipcc --genco into a code
+// object that is cached on disk (keyed by the automaton image), loaded with hipModuleLoad and launched
+// with hipModuleLaunchKernel.  Everything here is optional: if generation, compilation or loading
+// fails the launcher uses the generic kernel of kernels.hip (still on the GPU).
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <spawn.h>
+#include <sys/stat.h>
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "mfa_internal.h"
+
+extern char** environ;
+
+namespace mfa {
+
+static const char* kGeneratorVersion = "jit-2";
+
+static std::string cache_dir() {
+    if (const char* e = getenv("MFA_JIT_CACHE")) return e;
+    Dl_info info;
+    if (dladdr((void*)&cache_dir, &info) && info.dli_fname) {
+        std::string p = info.dli_fname;
+        size_t slash = p.rfind('/');
+        return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/jit_cache";
+    }
+    return "/tmp/mfa_jit_cache";
+}
+
+static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
+    const uint8_t* p = (const uint8_t*)data;
+    for (size_t k = 0; k < n; k++) { h ^= p[k]; h *= 1099511628211ull; }
+    return h;
+}
+
+static std::string image_key(const HostImage& img) {
+    uint64_t h = 1469598103934665603ull;
+    h = fnv1a(kGeneratorVersion, strlen(kGeneratorVersion), h);
+    h = fnv1a(&img.h, sizeof img.h, h);
+    h = fnv1a(img.edge_begin.data(), img.edge_begin.size() * 4, h);
+    h = fnv1a(img.edges.data(), img.edges.size() * sizeof(mfa_blob_edge), h);
+    char buf[32];
+    snprintf(buf, sizeof buf, "%016llx", (unsigned long long)h);
+    return buf;
+}
+
+bool jit_enabled(const HostImage& img) {
+    const char* e = getenv("MFA_JIT");
+    if (e && e[0] == '0') return false;
+    return img.h.kind == MFA_KIND_MFA && jit_slot_registers(img) <= 224;
+}
+
+static bool file_exists(const std::string& p) {
+    struct stat st;
+    return stat(p.c_str(), &st) == 0 && st.st_size > 0;
+}
+
+// generate + compile into the cache (host-only, no GPU needed); returns the code-object path or ""
+std::string jit_compile(const HostImage& img, std::string* err) {
+    if (!jit_enabled(img)) { if (err) *err = "automaton too large for the specialised kernel"; return ""; }
+    const std::string dir = cache_dir(), key = image_key(img);
+    const std::string src = dir + "/" + key + ".hip", obj = dir + "/" + key + ".hsaco";
+    if (file_exists(obj)) return obj;
+    mkdir(dir.c_str(), 0755);
+    {
+        std::ofstream f(src);
+        if (!f.is_open()) { if (err) *err = "cannot write " + src; return ""; }
+        f << jit_generate_source(img);
+    }
+    const char* hipcc = getenv("MFA_HIPCC");
+    std::string cc = hipcc ? hipcc : "/opt/rocm/bin/hipcc";
+    static std::atomic<unsigned> serial{0};
+    char tmpl[64];
+    snprintf(tmpl, sizeof tmpl, ".tmp%d_%u", (int)getpid(), serial.fetch_add(1));
+    std::string tmp = obj + tmpl, log = tmp + ".log";
+    std::string cmd = cc + " --genco --offload-arch=gfx950 -O3 -std=c++17 -o '" + tmp + "' '" + src + "' > '" + log + "' 2>&1";
+    const char* argv[] = {"/bin/sh", "-c", cmd.c_str(), nullptr};
+    pid_t pid;
+    if (posix_spawn(&pid, "/bin/sh", nullptr, nullptr, (char* const*)argv, environ) != 0) {
+        if (err) *err = "cannot start the compiler";
+        return "";
+    }
+    int status = 0;
+    if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0 || !file_exists(tmp)) {
+        unlink(tmp.c_str());
+        if (file_exists(obj)) { unlink(log.c_str()); return obj; }      // another thread or process got there first
+        if (err) *err = "hipcc failed, see " + log;
+        return "";
+    }
+    rename(tmp.c_str(), obj.c_str());
+    unlink(log.c_str());
+    return obj;
+}
+
+// caller holds the image mutex and has set the device
+bool jit_load(const HostImage& img, DeviceState& ds) {
+    if (ds.jit_tried) return ds.jit_fn != nullptr;
+    ds.jit_tried = true;
+    std::string err;
+    std::string obj = jit_compile(img, &err);
+    if (obj.empty()) {
+        if (jit_enabled(img)) fprintf(stderr, "mfa_hip: specialised kernel unavailable (%s); using the generic kernel\n", err.c_str());
+        return false;
+    }
+    hipModule_t mod = nullptr;
+    hipFunction_t fn = nullptr;
+    if (hipModuleLoad(&mod, obj.c_str()) != hipSuccess || hipModuleGetFunction(&fn, mod, "mfa_jit_kernel") != hipSuccess) {
+        fprintf(stderr, "mfa_hip: cannot load %s; using the generic kernel\n", obj.c_str());
+        if (mod) (void)hipModuleUnload(mod);
+        return false;
+    }
+    int blocks = 0;
+    if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64, 0) != hipSuccess || blocks <= 0) blocks = 4;
+    ds.jit_mod = mod; ds.jit_fn = fn; ds.jit_waves_per_cu = blocks > 32 ? 32 : blocks;
+    return true;
+}
+
+int launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
+                   void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(ds.d_counter, 0, sizeof(unsigned long long), s);
+    if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
+    uint64_t grid = (uint64_t)ds.n_cus * ds.jit_waves_per_cu, want = (n + 63) / 64;
+    if (grid > want) grid = want;
+    if (grid == 0) grid = 1;
+    void* args[] = {(void*)&d_bytes, (void*)&d_offsets, (void*)&n, (void*)&d_results, (void*)&ds.d_counter};
+    if (ds.timed) (void)hipEventRecord((hipEvent_t)ds.ev_start, s);
+    e = hipModuleLaunchKernel((hipFunction_t)ds.jit_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, s, args, nullptr);
+    if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
+    if (ds.timed) (void)hipEventRecord((hipEvent_t)ds.ev_stop, s);
+    return MFA_OK;
+}
+
+void jit_unload(DeviceState& ds) {
+    if (ds.jit_mod) (void)hipModuleUnload((hipModule_t)ds.jit_mod);
+    ds.jit_mod = nullptr; ds.jit_fn = nullptr;
+}
+
+}  // namespace mfa

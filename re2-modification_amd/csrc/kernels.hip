@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mfa_internal.h"
+#include "device_common.h"
 
 namespace mfa {
 
@@ -34,11 +35,7 @@ namespace mfa {
         if (e_ != hipSuccess) { set_last_hip_error((int)e_); return MFA_ERR_HIP; } \
     } while (0)
 
-static constexpr uint32_t kEmpty = 0xffffffffu;
-
-// flags word of a slot: per cell c (0-based) 8 bits at 8*c
-static constexpr uint32_t F_PRESENT = 1u, F_OPEN = 2u, F_READ = 4u, F_UNI = 8u;   // + char in bits 8..15 of a 16-bit field
-// With K <= 4 cells we use two flag words of 2 x 16 bits: cell c lives in word c/2, bits 16*(c%2)..
+static constexpr uint32_t kEmpty = MFA_EMPTY;
 
 template <int K>
 struct Mem {                 // the memory of one state, in registers
@@ -77,58 +74,6 @@ __device__ __forceinline__ uint32_t first_name(const Mem<K>& m) {
     return 0u;
 }
 
-// ---- input access -------------------------------------------------------------------------------
-struct Input {
-    const uint8_t* bytes;    // whole batch
-    uint64_t       base;     // offset of this lane's string
-    uint32_t       len;
-    // one cached aligned 16-byte block
-    uint64_t       blk;      // byte offset of the cached block (multiple of 16), ~0 = none
-    uint4          data;
-};
-
-template <bool REV>
-__device__ __forceinline__ uint64_t scan_addr(const Input& in, uint32_t j) {
-    return in.base + (REV ? (uint64_t)(in.len - 1u - j) : (uint64_t)j);
-}
-
-__device__ __forceinline__ uint32_t cached_byte(Input& in, uint64_t addr) {
-    uint64_t blk = addr & ~(uint64_t)15;
-    if (blk != in.blk) {
-        in.data = *reinterpret_cast<const uint4*>(in.bytes + blk);
-        in.blk = blk;
-    }
-    uint32_t o = (uint32_t)addr & 15u;
-    uint32_t w = (o & 8u) ? ((o & 4u) ? in.data.w : in.data.z) : ((o & 4u) ? in.data.y : in.data.x);
-    return (w >> ((o & 3u) * 8u)) & 0xffu;
-}
-
-// equality of scan[a, a+l) and scan[b, b+l): the two value spans of a cell read (mfa.cpp:179-191)
-template <bool REV>
-__device__ __forceinline__ bool spans_equal(const Input& in, uint32_t a, uint32_t b, uint32_t l) {
-    // in memory both spans are ascending byte ranges
-    const uint8_t* pa = in.bytes + (REV ? in.base + (in.len - a - l) : in.base + a);
-    const uint8_t* pb = in.bytes + (REV ? in.base + (in.len - b - l) : in.base + b);
-    uint32_t k = 0;
-    for (; k + 8 <= l; k += 8) {
-        uint64_t x, y;
-        __builtin_memcpy(&x, pa + k, 8);
-        __builtin_memcpy(&y, pb + k, 8);
-        if (x != y) return false;
-    }
-    for (; k < l; k++)
-        if (pa[k] != pb[k]) return false;
-    return true;
-}
-
-// exclusive end (scan index) of the run of byte `c` that starts at scan index i
-template <bool REV>
-__device__ __forceinline__ uint32_t run_end_from(const Input& in, uint32_t i, uint32_t c) {
-    uint32_t j = i + 1;
-    while (j < in.len && in.bytes[scan_addr<REV>(in, j)] == c) j++;
-    return j;
-}
-
 // ---- the walk -----------------------------------------------------------------------------------
 template <int K, bool REV, bool LDS_SLOTS>
 struct Walker {
@@ -143,8 +88,6 @@ struct Walker {
     uint32_t i;              // step index (scan position)
     uint32_t ch;             // scan[i]
     bool     final_pass;     // i == len
-    // cached run of equal bytes: scan[run_lo, run_hi) == run_ch, maximal to the right
-    uint32_t run_lo, run_hi, run_ch;
 
     __device__ __forceinline__ void load_mem(uint32_t buf, uint32_t node, Mem<K>& m) const {
 #pragma unroll
@@ -209,23 +152,6 @@ struct Walker {
         return pred && needed <= in.len - i;
     }
 
-    // does scan[i, i+l) equal the value of cell (start,len=l,flags)?   (mfa.cpp:178-187)
-    __device__ __forceinline__ bool read_matches(uint32_t start, uint32_t l, uint32_t fl) {
-        if (in.len - i < l) return false;
-        if (l == 0u) return true;
-        if (fl & F_UNI) {                                  // value is one byte repeated: compare against the run at i
-            uint32_t c = (fl >> 8) & 0xffu;
-            if (c != ch) return false;
-            if (l == 1u) return true;
-            if (!(run_ch == c && run_lo <= i && i < run_hi)) {
-                run_hi = run_end_from<REV>(in, i, c);
-                run_lo = i; run_ch = c;
-            }
-            return run_hi - i >= l;
-        }
-        return spans_equal<REV>(in, start, i, l);
-    }
-
     // MFA::evaluateState (mfa.cpp:136-200) for the lanes in `live`, all of which sit on `node`
     // with state (pos, m).  LEVEL = recursion depth through "unset cell" edges (mfa.cpp:148-160).
     template <int LEVEL>
@@ -281,7 +207,8 @@ struct Walker {
 #pragma unroll
                 for (int c = 0; c < K; c++)
                     if (c == d) { vs = m.start[c]; vl = m.len[c]; vf = m.fl[c]; if (rd) m.fl[c] |= F_READ; }
-                bool ok = rd && read_matches(vs, vl, vf);
+                bool ok = false;
+                if (rd) ok = read_matches<REV>(in, i, ch, vs, vl, vf);
                 if (__any(ok)) {
                     apply_actions(t, actions, i, vl, (vf & F_UNI) != 0u, (vf >> 8) & 0xffu);
                     insert(ok, target, ((pos + vl) << 4) | first_name(t), Q, R, t);
@@ -301,9 +228,8 @@ struct Walker {
     }
 
     __device__ __forceinline__ void start_string(uint64_t base, uint32_t len) {
-        in.base = base; in.len = len; in.blk = ~(uint64_t)0;
+        input_reset(in, base, len);
         i = 0; accept = false; active = true;
-        run_lo = run_hi = 0; run_ch = 0x100u;
         clear_lane_slots();
         *S.at(curbuf, g.start, 0) = 0u;                            // (pos 0, start, {})  mfa.cpp:217-219
 #pragma unroll
@@ -317,7 +243,7 @@ struct Walker {
     __device__ __forceinline__ bool step() {
         final_pass = (i == in.len);
         ch = 0x100u;
-        if (active && !final_pass) ch = cached_byte(in, scan_addr<REV>(in, i));
+        if (active && !final_pass) ch = stream_byte<REV>(in, i);
         any_next = false;
         for (uint32_t n = 0; n < g.n_nodes; n++) {
             uint32_t P = active ? *S.at(curbuf, n, 0) : kEmpty;
@@ -352,9 +278,10 @@ mfa_walk_kernel(DevImg g, const uint8_t* __restrict__ bytes, const uint64_t* __r
     if (LDS_SLOTS) w.S.base = lds + lane;
     else w.S.base = scratch + (size_t)blockIdx.x * (2u * g.n_nodes * SlotLayout<K>::W * 64u) + lane;
     w.in.bytes = bytes;
+    w.in.total16 = (offsets[n] + 15u) & ~(uint64_t)15;
+    input_reset(w.in, 0, 0);
     w.curbuf = 0;
-    w.active = false; w.accept = false; w.i = 0; w.in.len = 0; w.in.base = 0; w.in.blk = ~(uint64_t)0;
-    w.run_lo = w.run_hi = 0; w.run_ch = 0x100u;
+    w.active = false; w.accept = false; w.i = 0;
     uint64_t sid = 0;
     bool exhausted = false;
     for (;;) {

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <map>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/mfa_hip.h"
@@ -55,6 +56,11 @@ struct DeviceState {
     void*               ev_stop  = nullptr;
     bool                timed = false;
     int                 n_cus = 0;
+    // specialised kernel (jit.hip), if one is loaded for this device
+    bool                jit_tried = false;
+    void*               jit_mod = nullptr;     // hipModule_t
+    void*               jit_fn  = nullptr;     // hipFunction_t
+    int                 jit_waves_per_cu = 0;
 };
 
 }  // namespace mfa
@@ -63,6 +69,7 @@ struct mfa_image {
     mfa::HostImage                    host;
     std::mutex                        mu;
     std::map<int, mfa::DeviceState>   dev;
+    uint32_t                          last_kernel = 0;   // MFA_KERNEL_*
 };
 
 namespace mfa {
@@ -73,6 +80,15 @@ int launch_mfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_byte
 int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream);
 int device_prepare(mfa_image* img, int device, DeviceState** out);
+// specialised kernels (jit_gen.cpp, jit.hip)
+uint32_t    jit_slot_registers(const HostImage& img);
+std::string jit_generate_source(const HostImage& img);
+bool        jit_enabled(const HostImage& img);
+std::string jit_compile(const HostImage& img, std::string* err);
+bool        jit_load(const HostImage& img, DeviceState& ds);
+void        jit_unload(DeviceState& ds);
+int         launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
+                           void* stream);
 void device_release(DeviceState& ds);
 void set_last_hip_error(int e);
 

@@ -11,9 +11,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmfa_hip.so")
 
 OK = 0
-ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_TOO_LONG = -1, -2, -3, -4, -5, -6, -7
+KERNEL_NONE, KERNEL_GENERIC, KERNEL_SPECIALISED, KERNEL_TABLE = 0, 1, 2, 3
+ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_TOO_LONG, ERR_JIT = -1, -2, -3, -4, -5, -6, -7, -8
 
-EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_match_batch",
+EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_image_specialize", "mfa_match_batch",
            "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_device_count", "mfa_last_hip_error", "mfa_strerror",
            "mfa_version"]
 
@@ -29,7 +30,7 @@ class MfaError(RuntimeError):
 
 class ImageInfo(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in
-                ("kind", "is_reversed", "n_nodes", "n_edges", "n_cells", "dfa_states", "byte_classes", "reserved")]
+                ("kind", "is_reversed", "n_nodes", "n_edges", "n_cells", "dfa_states", "byte_classes", "last_kernel")]
 
 
 _lib = None
@@ -56,6 +57,7 @@ def lib():
         L.mfa_image_destroy.restype = None
         L.mfa_image_get_info.argtypes = [vp, ctypes.POINTER(ImageInfo)]
         L.mfa_image_prepare.argtypes = [vp, i32]
+        L.mfa_image_specialize.argtypes = [vp]
         L.mfa_match_batch.argtypes = [vp, vp, vp, u64, vp, i32, vp]
         L.mfa_match_batch_host.argtypes = [vp, vp, vp, u64, vp, i32]
         L.mfa_last_kernel_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
@@ -83,6 +85,15 @@ class Image:
         out = ImageInfo()
         _check(lib().mfa_image_get_info(self._h, ctypes.byref(out)), "mfa_image_get_info")
         return {n: getattr(out, n) for n, _ in ImageInfo._fields_}
+
+    def specialize(self):
+        """Generate and compile the automaton-specific kernel into the on-disk cache (no GPU needed).
+        Returns False when the automaton is too large for a specialised kernel."""
+        rc = lib().mfa_image_specialize(self._h)
+        if rc == ERR_UNSUPPORTED:
+            return False
+        _check(rc, "mfa_image_specialize")
+        return True
 
     def prepare(self, device=0):
         _check(lib().mfa_image_prepare(self._h, device), "mfa_image_prepare")

@@ -26,9 +26,17 @@ def gpu_match(img, strings):
     return res.cpu().numpy()
 
 
+@pytest.mark.parametrize("jit", ["specialised", "generic"])
 @pytest.mark.parametrize("auto", MANIFEST["automata"], ids=lambda a: a["name"])
-def test_golden(auto):
+def test_golden(auto, jit, monkeypatch):
+    """Both MFA kernels: the automaton-specific one (where the automaton is small enough) and the
+    table-driven one (MFA_JIT=0)."""
     blob = image.blob_from_dump(oracle_lib.load_dump(auto["name"]))
+    is_mfa = image.blob_info(blob)["kind"] == image.KIND_MFA
+    if jit == "generic":
+        if not is_mfa:
+            pytest.skip("memory-less automata have one kernel")
+        monkeypatch.setenv("MFA_JIT", "0")
     img = capi.Image(blob)
     for sset in auto["sets"]:
         strings = oracle_lib.load_set(sset)
@@ -37,6 +45,14 @@ def test_golden(auto):
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, "%s/%s: %d mismatches, first %r want %d got %d" % (
             auto["name"], sset, bad.size, strings[bad[0]], want[bad[0]], got[bad[0]])
+    kern = img.info()["last_kernel"]
+    if not is_mfa:
+        assert kern == capi.KERNEL_TABLE
+    elif jit == "generic":
+        assert kern == capi.KERNEL_GENERIC
+    else:
+        small = (image.blob_info(blob)["n_nodes"] - 1) * (1 + 3 * max(1, image.blob_info(blob)["n_cells"])) * 2 <= 224
+        assert kern == (capi.KERNEL_SPECIALISED if small else capi.KERNEL_GENERIC)
     img.close()
 
 
