@@ -24,6 +24,9 @@
 // (mfa.cpp:138-140,143-147): it is an accept flag, and once set it stays set.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "mfa_internal.h"
 #include "device_common.h"
 
@@ -308,9 +311,13 @@ mfa_walk_kernel(DevImg g, const uint8_t* __restrict__ bytes, const uint64_t* __r
 }
 
 // ---- table walk for memory-less automata -------------------------------------------------------
-// One string per lane; the transition table ([state][class], 16-bit) and the byte-class map sit
-// in LDS.  State 0 is the empty set: absorbing and rejecting, the reference's early `break`
-// (automata.cpp:186-188,196-198).
+// One string per lane.  LDS holds one fused table: next[state][byte] (16-bit entries, the state
+// pre-multiplied by the row stride), so a step is: extract byte, OR it into the state word, one
+// ds_read_u16.  Rows are padded by one dword so that equal bytes in different states fall into
+// different banks.  State 0 is the empty set: absorbing and rejecting, the reference's early
+// `break` (automata.cpp:186-188,196-198).  Input is read 16 bytes per lane per load.
+static constexpr uint32_t kDfaRow = 258;     // 16-bit entries per state row (256 + 2 pad)
+
 template <bool REV>
 __global__ void __launch_bounds__(256)
 dfa_walk_kernel(const uint16_t* __restrict__ trans, const uint8_t* __restrict__ accept_tab,
@@ -318,21 +325,159 @@ dfa_walk_kernel(const uint16_t* __restrict__ trans, const uint8_t* __restrict__ 
                 const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
                 uint8_t* __restrict__ results) {
     extern __shared__ uint32_t lds[];
-    uint16_t* s_trans = reinterpret_cast<uint16_t*>(lds);
-    uint8_t*  s_cls   = reinterpret_cast<uint8_t*>(s_trans + ((n_states * n_classes + 1u) & ~1u));
-    for (uint32_t k = threadIdx.x; k < n_states * n_classes; k += blockDim.x) s_trans[k] = trans[k];
-    for (uint32_t k = threadIdx.x; k < 256u; k += blockDim.x) s_cls[k] = byte_class[k];
+    uint16_t* s_next = reinterpret_cast<uint16_t*>(lds);             // [n_states][kDfaRow], entry = next_state * kDfaRow
+    for (uint32_t k = threadIdx.x; k < n_states * 256u; k += blockDim.x) {
+        const uint32_t st = k >> 8, b = k & 255u;
+        s_next[st * kDfaRow + b] = (uint16_t)(trans[st * n_classes + byte_class[b]] * kDfaRow);
+    }
     __syncthreads();
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t sid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sid < n; sid += stride) {
         const uint64_t b = offsets[sid], e = offsets[sid + 1];
-        uint32_t st = 1u;
+        uint32_t st = kDfaRow;                                        // state 1 = {start}
         if (!REV) {
-            for (uint64_t p = b; p < e && st != 0u; p++) st = s_trans[st * n_classes + s_cls[bytes[p]]];
+            uint64_t p = b;
+            while (p < e && st != 0u) {
+                const uint64_t blk = p & ~(uint64_t)15;
+                const uint4 d = load16(bytes, blk);
+                const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+                const uint32_t lo = (uint32_t)(p - blk), hi = (e - blk) < 16u ? (uint32_t)(e - blk) : 16u;
+                if (lo == 0u && hi == 16u) {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) st = s_next[st + ((w[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 16; k++) {
+                        const uint32_t nx = s_next[st + ((w[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+                        st = ((uint32_t)k >= lo && (uint32_t)k < hi) ? nx : st;
+                    }
+                }
+                p = blk + 16u;
+            }
         } else {
-            for (uint64_t p = e; p > b && st != 0u; p--) st = s_trans[st * n_classes + s_cls[bytes[p - 1]]];
+            uint64_t p = e;                                           // exclusive upper end, walk downwards
+            while (p > b && st != 0u) {
+                const uint64_t blk = (p - 1u) & ~(uint64_t)15;
+                const uint4 d = load16(bytes, blk);
+                const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+                const uint32_t hi = (uint32_t)(p - blk), lo = b > blk ? (uint32_t)(b - blk) : 0u;
+                if (lo == 0u && hi == 16u) {
+#pragma unroll
+                    for (int k = 15; k >= 0; k--) st = s_next[st + ((w[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+                } else {
+#pragma unroll
+                    for (int k = 15; k >= 0; k--) {
+                        const uint32_t nx = s_next[st + ((w[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+                        st = ((uint32_t)k >= lo && (uint32_t)k < hi) ? nx : st;
+                    }
+                }
+                p = blk;
+            }
         }
-        results[sid] = accept_tab[st];
+        results[sid] = accept_tab[st / kDfaRow];
+    }
+}
+
+// ---- tiled table walk -----------------------------------------------------------------------------
+// Same walk, input staged through LDS so that HBM is read in whole 128-byte lines: a wave owns 64
+// strings; each round, groups of 8 lanes fetch one 128-byte line of one string (8 x 16 B, a single
+// contiguous segment per group), the 64 lines are written to a padded LDS tile, and every lane then
+// reads its own string's line back with ds_read_b128.  The pad (144-byte row stride) keeps the 16
+// lanes of a ds_read_b128 group on distinct banks.
+//   PACKED: automata with <= 8 state sets and <= 7 literal byte classes keep the whole table in
+//   SGPRs -- one 32-bit word per class, 4 bits per state -- so a step is a byte compare/select
+//   (independent of the state) plus a 2-instruction dependent chain (shift, bit-field extract)
+//   instead of an LDS round trip.
+struct DfaPacked {
+    uint32_t n_lit;          // literal classes
+    uint32_t lit[7];         // their bytes
+    uint32_t tab[8];         // tab[c]: nibble s = next state of s on class c; tab[n_lit] = every other byte
+    uint32_t accept_mask;    // bit s = state s accepts
+};
+
+static constexpr uint32_t kTileRow = 144;    // bytes per string row in the LDS tile (128 + 16 pad)
+
+template <bool REV, bool PACKED, int NLIT>
+__global__ void __launch_bounds__(256)
+dfa_tiled_kernel(DfaPacked pk, const uint16_t* __restrict__ trans, const uint8_t* __restrict__ accept_tab,
+                 const uint8_t* __restrict__ byte_class, uint32_t n_states, uint32_t n_classes,
+                 const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
+                 uint8_t* __restrict__ results) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint8_t* tile = reinterpret_cast<uint8_t*>(lds) + wave * (64u * kTileRow);
+    uint16_t* s_next = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(lds) + 4u * 64u * kTileRow);
+    if (!PACKED) {
+        for (uint32_t k = threadIdx.x; k < n_states * 256u; k += blockDim.x) {
+            const uint32_t st = k >> 8, b = k & 255u;
+            s_next[st * kDfaRow + b] = (uint16_t)(trans[st * n_classes + byte_class[b]] * kDfaRow);
+        }
+        __syncthreads();
+    }
+    const uint64_t total16 = (offsets[n] + 15u) & ~(uint64_t)15;
+    const uint64_t n_waves = (uint64_t)gridDim.x * 4u;
+    uint32_t lit[NLIT > 0 ? NLIT : 1], tabs[NLIT + 1];
+#pragma unroll
+    for (int c = 0; c < NLIT; c++) lit[c] = pk.lit[c];
+#pragma unroll
+    for (int c = 0; c <= NLIT; c++) tabs[c] = pk.tab[c];
+    for (uint64_t w0 = ((uint64_t)blockIdx.x * 4u + wave) * 64u; w0 < n; w0 += n_waves * 64u) {
+        const uint64_t sid = w0 + lane;
+        const bool have = sid < n;
+        const uint64_t b = have ? offsets[sid] : 0, e = have ? offsets[sid + 1] : 0;
+        uint64_t p = REV ? e : b;                 // forward: next byte to consume; reverse: one past it
+        uint32_t st = PACKED ? 1u : kDfaRow;      // state 1 = {start}
+        for (;;) {
+            const bool active = have && st != 0u && (REV ? p > b : p < e);
+            if (!__any(active)) break;
+            const uint64_t line = (REV ? p - 1u : p) & ~(uint64_t)127;
+            // fetch: lane group g = lane>>3 serves strings g, g+8, ..., one 128-byte line each
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int src = k * 8 + (int)(lane >> 3);
+                const uint32_t lo = __shfl((uint32_t)line, src), hi = __shfl((uint32_t)(line >> 32), src);
+                const int act = __shfl((int)active, src);
+                const uint64_t addr = (((uint64_t)hi << 32) | lo) + (lane & 7u) * 16u;
+                v[k] = (act && addr < total16) ? load16(bytes, addr) : make_uint4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t src = (uint32_t)k * 8u + (lane >> 3);
+                *reinterpret_cast<uint4*>(tile + src * kTileRow + (lane & 7u) * 16u) = v[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            // walk this lane's line
+            const uint32_t lo_b = active ? (uint32_t)((REV ? (b > line ? b - line : 0) : p - line)) : 0u;
+            const uint32_t hi_b = active ? (uint32_t)((REV ? p - line : (e - line < 128u ? e - line : 128u))) : 0u;
+            const bool full = __all(!active || (lo_b == 0u && hi_b == 128u));
+#pragma unroll 1
+            for (int q = 0; q < 8; q++) {
+                const int qq = REV ? 7 - q : q;
+                const uint4 d = *reinterpret_cast<const uint4*>(tile + lane * kTileRow + (uint32_t)qq * 16u);
+                const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int kk = 0; kk < 16; kk++) {
+                    const int k = REV ? 15 - kk : kk;
+                    const uint32_t byte = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                    uint32_t nx;
+                    if (PACKED) {
+                        uint32_t sel = tabs[NLIT];
+#pragma unroll
+                        for (int c = 0; c < NLIT; c++) sel = (byte == lit[c]) ? tabs[c] : sel;
+                        nx = __builtin_amdgcn_ubfe(sel, st << 2, 4u);
+                    } else {
+                        nx = s_next[st + byte];
+                    }
+                    const uint32_t idx = (uint32_t)qq * 16u + (uint32_t)k;
+                    st = (full || (idx >= lo_b && idx < hi_b)) ? (active ? nx : st) : st;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (active) p = REV ? line : line + 128u;
+            if (!REV && p > e) p = e;
+        }
+        if (have) results[sid] = PACKED ? (uint8_t)((pk.accept_mask >> st) & 1u) : accept_tab[st / kDfaRow];
     }
 }
 
@@ -396,12 +541,70 @@ int launch_mfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_byte
     return MFA_ERR_UNSUPPORTED;
 }
 
+static bool make_packed(const HostImage& img, DfaPacked& pk) {
+    if (img.dfa_states > 8 || img.n_classes > 8 || img.n_classes < 1) return false;
+    std::memset(&pk, 0, sizeof pk);
+    pk.n_lit = img.n_classes - 1;                      // tabulate_nfa: literal classes first, "every other byte" last
+    for (uint32_t c = 0; c < pk.n_lit; c++) {
+        int rep = -1;
+        for (int b = 0; b < 256; b++)
+            if (img.byte_class[b] == c) { if (rep >= 0) return false; rep = b; }
+        if (rep < 0) return false;
+        pk.lit[c] = (uint32_t)rep;
+    }
+    for (uint32_t c = 0; c < img.n_classes; c++)
+        for (uint32_t s = 0; s < img.dfa_states; s++) pk.tab[c] |= (uint32_t)img.dfa_trans[s * img.n_classes + c] << (4 * s);
+    for (uint32_t s = 0; s < img.dfa_states; s++) pk.accept_mask |= (uint32_t)(img.dfa_accept[s] != 0) << s;
+    return true;
+}
+
+template <bool REV, bool PACKED, int NLIT>
+static int launch_dfa_tiled(const HostImage& img, DeviceState& ds, const DfaPacked& pk, const uint8_t* d_bytes,
+                            const uint64_t* d_offsets, uint64_t n, uint8_t* d_results, hipStream_t s) {
+    size_t lds = 4 * 64 * kTileRow + (PACKED ? 0 : (size_t)img.dfa_states * kDfaRow * sizeof(uint16_t));
+    uint64_t blocks = (n + 255) / 256, cap = (uint64_t)ds.n_cus * 4;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    auto kern = dfa_tiled_kernel<REV, PACKED, NLIT>;
+    HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_start, s));
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, pk, ds.d_dfa_trans, ds.d_dfa_accept, ds.d_byte_class,
+                       img.dfa_states, img.n_classes, d_bytes, d_offsets, n, d_results);
+    HIP_TRY(hipGetLastError());
+    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_stop, s));
+    return MFA_OK;
+}
+
 int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    size_t tab = ((size_t)img.dfa_states * img.n_classes + 1) & ~(size_t)1;
-    size_t lds = tab * sizeof(uint16_t) + 256;
-    if (lds > 160 * 1024) return MFA_ERR_UNSUPPORTED;
+    if ((size_t)img.dfa_states * kDfaRow > 0xffffu) return MFA_ERR_UNSUPPORTED;      // 16-bit pre-multiplied states
+    {
+        const char* mode = getenv("MFA_DFA_KERNEL");                                 // "simple" selects the untiled walk
+        if (!(mode && mode[0] == 's')) {
+            DfaPacked pk;
+            // measured on MI355X, (a|b)*abb, 1M x 1 KiB: table in LDS 3.25 TB/s, table packed in SGPRs 2.65 TB/s,
+            // untiled 1.0 TB/s -- the LDS table is the default, "packed" selects the SGPR form
+            const bool packed = mode && mode[0] == 'p' && make_packed(img, pk);
+            if ((size_t)img.dfa_states * kDfaRow * 2 + 4 * 64 * kTileRow <= 64 * 1024) {
+#define MFA_DFA_GO(REVV, P, NL) return launch_dfa_tiled<REVV, P, NL>(img, ds, pk, d_bytes, d_offsets, n, d_results, s)
+                if (packed && pk.n_lit <= 4) {
+                    if (img.h.is_reversed) {
+                        switch (pk.n_lit) { case 0: MFA_DFA_GO(true, true, 0); case 1: MFA_DFA_GO(true, true, 1); case 2: MFA_DFA_GO(true, true, 2);
+                                            case 3: MFA_DFA_GO(true, true, 3); default: MFA_DFA_GO(true, true, 4); }
+                    } else {
+                        switch (pk.n_lit) { case 0: MFA_DFA_GO(false, true, 0); case 1: MFA_DFA_GO(false, true, 1); case 2: MFA_DFA_GO(false, true, 2);
+                                            case 3: MFA_DFA_GO(false, true, 3); default: MFA_DFA_GO(false, true, 4); }
+                    }
+                }
+                if (img.h.is_reversed) MFA_DFA_GO(true, false, 0);
+                MFA_DFA_GO(false, false, 0);
+#undef MFA_DFA_GO
+            }
+        }
+    }
+    size_t lds = (size_t)img.dfa_states * kDfaRow * sizeof(uint16_t);
+    if (lds > 64 * 1024) return MFA_ERR_UNSUPPORTED;
     uint64_t blocks = (n + 255) / 256;
     uint64_t cap = (uint64_t)ds.n_cus * 8;
     if (blocks > cap) blocks = cap;
