@@ -26,7 +26,7 @@ sys.path.insert(0, os.path.join(ROOT, "re2-modification_amd"))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from mfa_amd import capi, corpus, image  # noqa: E402
+from mfa_amd import capi, corpus, image, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 GOLDEN = os.path.join(ROOT, "tests", "golden")
@@ -141,7 +141,6 @@ def main():
         total_bytes += nbytes
         total_strings += n_per
     results = torch.zeros(total_strings, dtype=torch.uint8, device=device)
-    bit_w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=device)
     n_bitmap = (total_strings + 7) // 8
     gathered = [torch.empty(n_bitmap, dtype=torch.uint8, device=device) for _ in range(world)] if (dist and rank == 0) else None
     kernel_ms = {ex: [] for ex in shards}
@@ -167,9 +166,7 @@ def main():
                 main.wait_event(ev_done[ex])
             pos += sh["n"]
         ev_join.record(main)
-        pad = (-total_strings) % 8
-        r = torch.cat([results, results.new_zeros(pad)]) if pad else results
-        bitmap = (r.view(-1, 8) * bit_w).sum(dim=1, dtype=torch.uint8)
+        bitmap = sharding.pack_bitmap(results)
         if dist:
             dist.gather(bitmap, gathered, dst=0)      # RCCL over xGMI: the path's only exchange
         if record:
