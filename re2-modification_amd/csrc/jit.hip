@@ -22,7 +22,7 @@ extern char** environ;
 
 namespace mfa {
 
-static const char* kGeneratorVersion = "jit-2";
+static const char* kGeneratorVersion = "jit-7";
 
 static std::string cache_dir() {
     if (const char* e = getenv("MFA_JIT_CACHE")) return e;
@@ -120,6 +120,7 @@ bool jit_load(const HostImage& img, DeviceState& ds) {
     int blocks = 0;
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64, 0) != hipSuccess || blocks <= 0) blocks = 4;
     ds.jit_mod = mod; ds.jit_fn = fn; ds.jit_waves_per_cu = blocks > 32 ? 32 : blocks;
+    ds.jit_words = jit_slot_registers(img) / 2;
     return true;
 }
 
@@ -131,7 +132,19 @@ int launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_of
     uint64_t grid = (uint64_t)ds.n_cus * ds.jit_waves_per_cu, want = (n + 63) / 64;
     if (grid > want) grid = want;
     if (grid == 0) grid = 1;
-    void* args[] = {(void*)&d_bytes, (void*)&d_offsets, (void*)&n, (void*)&d_results, (void*)&ds.d_counter};
+    const char* ae = getenv("MFA_ACCEL");
+    uint32_t accel = (ae && ae[0] == '0') ? 0u : 1u;                  // MFA_ACCEL=0: execute every step (A/B testing)
+    // probe storage: three slot-set images per wave (jit_gen.cpp)
+    const size_t need = (size_t)grid * 3u * ds.jit_words * 64u * sizeof(uint32_t);
+    if (need > ds.scratch_bytes) {
+        if (ds.d_scratch) (void)hipFree(ds.d_scratch);
+        ds.d_scratch = nullptr; ds.scratch_bytes = 0;
+        e = hipMalloc((void**)&ds.d_scratch, need);
+        if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
+        ds.scratch_bytes = need;
+    }
+    void* args[] = {(void*)&d_bytes, (void*)&d_offsets, (void*)&n, (void*)&d_results, (void*)&ds.d_counter, (void*)&accel,
+                    (void*)&ds.d_scratch};
     if (ds.timed) (void)hipEventRecord((hipEvent_t)ds.ev_start, s);
     e = hipModuleLaunchKernel((hipFunction_t)ds.jit_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, s, args, nullptr);
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }

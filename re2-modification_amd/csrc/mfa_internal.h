@@ -61,6 +61,7 @@ struct DeviceState {
     void*               jit_mod = nullptr;     // hipModule_t
     void*               jit_fn  = nullptr;     // hipFunction_t
     int                 jit_waves_per_cu = 0;
+    uint32_t            jit_words = 0;         // words per slot set of the specialised kernel
 };
 
 }  // namespace mfa

@@ -80,3 +80,45 @@ def test_cli_match_contract(tmp_path):
         assert p.returncode == 0, p.stderr
         expect = auto["header"].encode() + b"".join(b"%d\n" % b for b in want)
         assert p.stdout == expect, name
+
+
+def _structured_strings(ex, rng, count, max_len):
+    """Attack-like inputs with long runs: pumped strings of random size with a few bytes flipped, and
+    concatenations of runs -- what run acceleration jumps over."""
+    from mfa_amd import corpus
+    regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+    out = []
+    for k in range(count):
+        kind = k % 4
+        n = int(rng.integers(30, max_len))
+        if kind < 2:
+            s = bytearray((prefix + corpus.pumped_string(n, pump) + (suffix if k % 3 else "")).encode())
+            for _ in range(int(rng.integers(0, 4)) if kind == 1 else 0):
+                s[int(rng.integers(0, len(s)))] = int(rng.choice(list(b"abc")))
+        elif kind == 2:
+            s = bytearray()
+            while len(s) < n:
+                s += bytes([int(rng.choice(list(b"aab")))]) * int(rng.integers(1, max(2, n // 3)))
+        else:
+            s = bytearray(b"a" * n)
+            if rng.random() < 0.5:
+                s += bytes(rng.choice(list(b"abc"), size=int(rng.integers(1, 4))).tolist())
+        out.append(bytes(s))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["plain", "bnf", "reverse"])
+@pytest.mark.parametrize("ex", range(1, 11))
+def test_long_runs_against_oracle(ex, mode):
+    """Strings far longer than the golden vectors (up to 6 KiB, with long runs of equal bytes) against the
+    CPU restatement: covers run acceleration in the specialised kernels and the run cache in both."""
+    name = "ex%d_%s" % (ex, mode)
+    blob = image.blob_from_dump(oracle_lib.load_dump(name))
+    rng = np.random.default_rng(1000 * ex + len(mode))
+    strings = _structured_strings(ex, rng, 96, 6000)
+    want = oracle_lib.OracleImage(blob).match(strings)
+    img = capi.Image(blob)
+    got = gpu_match(img, strings)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "%s: %d mismatches, first len %d %r... want %d" % (
+        name, bad.size, len(strings[bad[0]]), strings[bad[0]][:60], want[bad[0]])
