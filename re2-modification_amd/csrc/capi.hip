@@ -65,7 +65,7 @@ int device_prepare(mfa_image* img, int device, DeviceState** out) {
         if (rc == MFA_OK) rc = up((void**)&ds.d_byte_class, h.byte_class, 256);
     }
     if (rc == MFA_OK) {
-        hipError_t e = hipMalloc((void**)&ds.d_counter, 64);
+        hipError_t e = hipMalloc((void**)&ds.d_counter, 128 + (getenv("MFA_STATS") ? (4u << 20) : 0));
         if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&ds.ev_start);
         if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&ds.ev_stop);
         if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }
@@ -202,6 +202,7 @@ int mfa_last_kernel_ms(mfa_image_t* img, int device, float* ms) {
     if (it == img->dev.end() || !it->second.timed) return MFA_ERR_INVALID_ARG;
     HIP_TRY(hipEventSynchronize((hipEvent_t)it->second.ev_stop));
     HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)it->second.ev_start, (hipEvent_t)it->second.ev_stop));
+    jit_print_stats(it->second, "last kernel");
     return MFA_OK;
 }
 

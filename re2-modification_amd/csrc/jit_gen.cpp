@@ -165,8 +165,16 @@ struct Gen {
                 o << ind << "    const U " << vs << " = " << s.S[d] << ", " << vl << " = " << s.L[d] << "; const uint32_t " << vf << " = flagv("
                   << s.F[d] << ", TB);\n";
                 o << ind << "    " << s.F[d] << " = sel(" << rd << ", konst<U>(" << vf << " | F_READ), " << s.F[d] << ");\n";
-                o << ind << "    bool " << ok << " = false;\n";
-                o << ind << "    if (" << rd << ") " << ok << " = read_matches_u<REV, U>(in, i, ch, " << vs << ", " << vl << ", " << vf << ", TB);\n";
+                o << ind << "    bool " << ok << " = false, cmp" << id << " = false;\n";
+                o << ind << "    if (" << rd << ") " << ok << " = read_pre_u<REV, U>(in, i, ch, " << vs << ", " << vl << ", " << vf << ", TB, cmp" << id << ");\n";
+                o << ind << "    for (unsigned long long sb = __ballot(cmp" << id << "); sb; sb &= sb - 1ull) {      // byte-wise comparisons: one lane's at a time, whole wave\n";
+                o << ind << "      const int L = __builtin_ctzll(sb);\n";
+                o << ind << "      const uint32_t ca = val(" << vs << "), cb = val(i), cl = val(" << vl << ");\n";
+                o << ind << "      const uint64_t pa = in.base + (REV ? (uint64_t)(in.len - ca - cl) : (uint64_t)ca), pb = in.base + (REV ? (uint64_t)(in.len - cb - cl) : (uint64_t)cb);\n";
+                o << ind << "      const bool r = coop_mem_equal(in.bytes, ((uint64_t)__shfl((uint32_t)(pa >> 32), L) << 32) | __shfl((uint32_t)pa, L),\n";
+                o << ind << "                                    ((uint64_t)__shfl((uint32_t)(pb >> 32), L) << 32) | __shfl((uint32_t)pb, L), __shfl(cl, L), threadIdx.x & 63u);\n";
+                o << ind << "      if ((threadIdx.x & 63u) == (uint32_t)L) " << ok << " = r;\n";
+                o << ind << "    }\n";
                 o << ind << "    if (__any(" << ok << ")) {\n";
                 apply_actions(t, e.actions, ok, "i", vl, "((" + vf + " & F_UNI) != 0u)", "((" + vf + " >> 8) & 0xffu)", ind + "      ");
                 insert(e.target, ok, "mkp(add(i, " + vl + "), " + fname(t) + ")", t, ind + "      ");
@@ -225,8 +233,8 @@ struct Gen {
     void emit_step() {
         const uint32_t N = g.h.n_nodes;
         o << "template <class U>\n__device__ __forceinline__ void mfa_step(SlotSet<U>& c, Input& in, const U i, const U len, const uint32_t ch,\n"
-             "                                         const bool final_pass, bool& accept, bool& any_next, int64_t& TB) {\n";
-        o << "  SlotSet<U> n;\n";
+             "                                         const bool final_pass, bool& accept, bool& any_next, tb_t& TB, uint32_t* nxt_mem) {\n";
+        o << "  NextSet<U> n(nxt_mem);\n";
         // ---- classify the current slots
         for (uint32_t n = 0; n < N; n++) {
             if (is_finish(n)) continue;
@@ -286,8 +294,9 @@ struct Gen {
         // ---- end of step
         o << "  any_next = false;\n";
         for (uint32_t n = 0; n < N; n++)
-            if (!is_finish(n)) o << "  any_next = any_next || ne(n.P" << n << ", konst<U>(MFA_EMPTY), TB);\n";
-        o << "  c = n;\n}\n\n";
+            if (!is_finish(n)) o << "  any_next = any_next || ne(U(n.P" << n << "), konst<U>(MFA_EMPTY), TB);\n";
+        for (const auto& w : slot_words()) o << "  c." << w << " = n." << w << ";\n";
+        o << "}\n\n";
     }
 
     std::string run() {
@@ -298,12 +307,38 @@ struct Gen {
         o << "template <class U> struct SlotSet {\n";
         for (const auto& w : words) o << "  U " << w << ";\n";
         o << "};\n\n";
+        // The set a step builds.  Plain steps keep it in registers.  Dual steps of larger automata would need
+        // four slot sets in registers at once (values and directions, current and next) and spill; their next
+        // set lives in LDS instead, [word][v|d][lane]: one bank per lane, conflict free.
+        const bool lds_next = words.size() > 24;
+        o << "#define NEXT_IN_LDS " << (lds_next ? 1 : 0) << "\n";
+        o << "struct LdsDual {\n  uint32_t* p;\n"
+             "  __device__ __forceinline__ operator Dual() const { return Dual{p[0], (int32_t)p[64]}; }\n"
+             "  __device__ __forceinline__ LdsDual& operator=(Dual d) { p[0] = d.v; p[64] = (uint32_t)d.d; return *this; }\n"
+             "  __device__ __forceinline__ LdsDual& operator=(const LdsDual& o) { return *this = (Dual)o; }\n};\n";
+        o << "template <class U> struct NextSet;\n";
+        o << "template <> struct NextSet<uint32_t> {\n";
+        for (const auto& w : words) o << "  uint32_t " << w << ";\n";
+        o << "  __device__ __forceinline__ explicit NextSet(uint32_t*) {}\n};\n";
+        if (lds_next) {
+            o << "template <> struct NextSet<Dual> {\n";
+            for (const auto& w : words) o << "  LdsDual " << w << ";\n";
+            o << "  __device__ __forceinline__ explicit NextSet(uint32_t* m) :";
+            for (size_t k = 0; k < words.size(); k++) o << (k ? ", " : " ") << words[k] << "{m + " << 2 * k << " * 64}";
+            o << " {}\n};\n\n";
+        } else {
+            o << "template <> struct NextSet<Dual> {\n";
+            for (const auto& w : words) o << "  Dual " << w << ";\n";
+            o << "  __device__ __forceinline__ explicit NextSet(uint32_t*) {}\n};\n\n";
+        }
         emit_step();
         // ---- kernel
         o << "extern \"C\" __global__ void __launch_bounds__(64)\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
              "const uint64_t* __restrict__ offsets, uint64_t n,\n               uint8_t* __restrict__ results, "
-             "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch) {\n";
+             "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats) {\n";
+        o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";
         o << "  const uint32_t lane = threadIdx.x & 63u;\n";
+        o << "#if NEXT_IN_LDS\n  __shared__ uint32_t nxt_lds[2 * N_WORDS * 64];\n  uint32_t* const nxt_mem = nxt_lds + lane;\n#else\n  uint32_t* const nxt_mem = nullptr;\n#endif\n";
         o << "  // probe storage of this wave, [array][word][lane]: SA = slots at probe start, later the direction d;\n"
              "  // SB = slots at the start of the dual period; SD = direction carried between dual steps\n";
         o << "  uint32_t* const SA = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u) + lane;\n";
@@ -312,54 +347,73 @@ struct Gen {
         o << "  in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;\n";
         o << "  bool active = false, exhausted = false, accept = false;\n  uint32_t i = 0, len = 0; uint64_t sid = 0;\n";
         o << "  // run acceleration: phase 0 idle, 1 = pp plain steps after saving the slots, 2 = pp dual steps\n";
-        o << "  uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1;\n  int64_t TBacc = 0;\n";
+        o << "  uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1;\n  tb_t TBacc = tb_init();\n";
         o << "  SlotSet<uint32_t> c;\n";
         for (const auto& w : words) o << "  c." << w << " = " << (w[0] == 'P' ? "MFA_EMPTY" : "0u") << ";\n";
         o << "  for (;;) {\n";
-        o << "    if (!active && !exhausted) {\n      for (;;) {\n        sid = atomicAdd(counter, 1ull);\n"
-             "        if (sid >= n) { exhausted = true; break; }\n        uint64_t b = offsets[sid], e = offsets[sid + 1];\n"
-             "        if (e - b > MFA_DEV_MAX_LEN) { results[sid] = 2; continue; }\n"
-             "        len = (uint32_t)(e - b); input_reset(in, b, len);\n"
-             "        i = 0; accept = false; active = true; phase = 0; probe_at = 0; backoff = 8; pp = 1; fails = 0; mult = 1;\n";
+        o << "    {\n      // hand strings to idle lanes: one atomic per wave, tickets dealt by lane rank\n"
+             "      const bool want = !active && !exhausted;\n      const unsigned long long wb = __ballot(want);\n"
+             "      if (wb) {\n        unsigned long long first = 0;\n"
+             "        if (lane == (uint32_t)__builtin_ctzll(wb)) first = atomicAdd(counter, (unsigned long long)__builtin_popcountll(wb));\n"
+             "        first = ((unsigned long long)__shfl((uint32_t)(first >> 32), __builtin_ctzll(wb)) << 32) | __shfl((uint32_t)first, __builtin_ctzll(wb));\n"
+             "        if (want) {\n          sid = first + (unsigned long long)__builtin_popcountll(wb & ((1ull << lane) - 1ull));\n"
+             "          if (sid >= n) exhausted = true;\n          else {\n            const uint64_t b = offsets[sid], e = offsets[sid + 1];\n"
+             "            if (e - b > MFA_DEV_MAX_LEN) results[sid] = 2;\n            else {\n"
+             "              len = (uint32_t)(e - b); input_reset(in, b, len);\n"
+             "              i = 0; accept = false; active = true; phase = 0; probe_at = 0; backoff = 8; pp = 1; fails = 0; mult = 1;\n";
         for (const auto& w : words)
-            o << "        c." << w << " = " << (w == "P" + num(g.h.start) ? "0u" : (w[0] == 'P' ? "MFA_EMPTY" : "0u")) << ";\n";
-        o << "        break;\n      }\n    }\n    if (!__any(active)) break;\n";
+            o << "              c." << w << " = " << (w == "P" + num(g.h.start) ? "0u" : (w[0] == 'P' ? "MFA_EMPTY" : "0u")) << ";\n";
+        o << "            }\n          }\n        }\n      }\n    }\n    if (!__any(active)) break;\n    st_iter++;\n";
         o << "    const bool final_pass = (i == len);\n    uint32_t ch = 0x100u;\n"
              "    if (active && !final_pass) ch = stream_byte<REV>(in, i);\n";
         // decide whether this lane starts a probe: it must sit in a long run of equal bytes
-        o << "    if (accel && active && !final_pass && phase == 0u && i >= probe_at) {\n"
+        o << "    // does this lane sit at the start of a block that looks periodic?  then find how far the periodic region goes\n"
+             "    uint32_t q = 0u;\n"
+             "    if (accel && active && !final_pass && phase == 0u && i >= probe_at) {\n"
              "      uint32_t rest;\n"
-             "      const uint32_t q = block_period<REV>(in, i, rest);\n"
+             "      q = block_period<REV>(in, i, rest);\n"
              "      probe_at = i + rest;                      // next look: first byte of the next block\n"
-             "      if (q != 0u && rest >= 8u) {\n"
-             "        if (!(in.per_q == q && in.per_lo <= i && i < in.per_hi)) { in.per_hi = q == 1u ? run_end_from<REV>(in, i, ch) : period_end_from<REV>(in, i, q); in.per_lo = i; in.per_q = q; }\n"
-             "        if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
-             "        pp = q * mult;\n"
-             "        if (pp > 16u) { mult = 1u; pp = q; }\n"
-             "        if (in.per_hi - i >= 4u * pp + 24u) {\n";
-        for (size_t k = 0; k < words.size(); k++) o << "          SA[" << k << " * 64] = c." << words[k] << ";\n";
-        o << "          phase = 1u; pk = 0u;\n        } else {\n          probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;\n        }\n      }\n    }\n";
-        o << "    bool any_next = false;\n    int64_t TB = (int64_t)1 << 40;\n";
+             "      if (rest < 8u) q = 0u;\n"
+             "    }\n"
+             "    bool need_scan = q != 0u && !(in.per_q == q && in.per_lo <= i && i < in.per_hi);\n"
+             "    if (REV) {\n"
+             "      if (need_scan) { in.per_hi = q == 1u ? run_end_from<REV>(in, i, ch) : period_end_from<REV>(in, i, q); in.per_lo = i; in.per_q = q; st_scan++; }\n"
+             "    } else {\n"
+             "      for (unsigned long long sb = __ballot(need_scan); sb; sb &= sb - 1ull) {          // one string at a time, all lanes scanning\n"
+             "        const int L = __builtin_ctzll(sb);\n"
+             "        const uint64_t sbase = ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L);\n"
+             "        const uint32_t r = coop_period_end_fwd(bytes, sbase, __shfl(len, L), __shfl(i, L), __shfl(q, L), lane);\n"
+             "        if (lane == (uint32_t)L) { in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++; }\n"
+             "      }\n"
+             "    }\n"
+             "    if (q != 0u) {\n"
+             "      if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
+             "      pp = q * mult;\n"
+             "      if (pp > 16u) { mult = 1u; pp = q; }\n"
+             "      if (in.per_hi - i >= 4u * pp + 24u) {\n";
+        for (size_t k = 0; k < words.size(); k++) o << "        SA[" << k << " * 64] = c." << words[k] << ";\n";
+        o << "        phase = 1u; pk = 0u; st_probe++;\n      } else {\n        probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;\n      }\n    }\n";
+        o << "    bool any_next = false;\n    tb_t TB = tb_init();\n";
         o << "    if (__any(phase == 2u)) {\n";
         o << "      // dual step: lanes in phase 2 carry the direction saved in SD, the others d = 0 (their TB is ignored)\n";
-        o << "      const bool p2 = phase == 2u;\n      SlotSet<Dual> dc;\n";
+        o << "      const bool p2 = phase == 2u;\n      SlotSet<Dual> dc;\n      st_dual++;\n";
         for (size_t k = 0; k < words.size(); k++)
             o << "      dc." << words[k] << " = Dual{c." << words[k] << ", p2 ? (int32_t)SD[" << k << " * 64] : 0};\n";
         o << "      const Dual di{i, (int32_t)pp}, dlen{len, 0};\n";
         o << "      in.dual_p = p2 ? pp : 0u;\n";
         o << "      (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the periodic region\n";
         o << "      (void)eq(di, dlen, TB);\n";
-        o << "      mfa_step<Dual>(dc, in, di, dlen, ch, final_pass, accept, any_next, TB);\n";
+        o << "      mfa_step<Dual>(dc, in, di, dlen, ch, final_pass, accept, any_next, TB, nxt_mem);\n";
         o << "      in.dual_p = 0u;\n";
         o << "      uint32_t skip = 0;\n";
-        o << "      if (p2) {\n        TBacc = TB < TBacc ? TB : TBacc;\n        pk++;\n";
-        o << "        if (pk == pp) {\n          bool same = !accept && any_next && TBacc > 1;\n";
+        o << "      if (p2) {\n        tb_min(TBacc, TB.a, TB.b);\n        pk++;\n";
+        o << "        if (pk == pp) {\n          const int64_t periods = tb_steps(TBacc);\n          bool same = !accept && any_next && periods > 1;\n";
         for (size_t k = 0; k < words.size(); k++)
             o << "          same = same && dc." << words[k] << ".d == (int32_t)SA[" << k << " * 64] && dc." << words[k] << ".v - SB[" << k
               << " * 64] == SA[" << k << " * 64];\n";
-        o << "          if (same) skip = (uint32_t)(TBacc - 1 < (int64_t)0x00ffffff ? TBacc - 1 : (int64_t)0x00ffffff);\n";
+        o << "          if (same) skip = (uint32_t)(periods - 1 < (int64_t)0x00ffffff ? periods - 1 : (int64_t)0x00ffffff);\n";
         o << "          phase = 0u;\n";
-        o << "          if (skip) { backoff = 8u; fails = 0u; }\n";
+        o << "          if (skip) { backoff = 8u; fails = 0u; st_hit++; st_skip += (unsigned long long)skip * pp; }\n";
         o << "          else { fails++; mult = mult % 8u + 1u; if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; } }\n";
         o << "        } else {\n";
         for (size_t k = 0; k < words.size(); k++) o << "          SD[" << k << " * 64] = (uint32_t)dc." << words[k] << ".d;\n";
@@ -369,7 +423,7 @@ struct Gen {
         o << "      else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);\n";
         o << "      if (phase == 1u) pk++;\n";
         o << "    } else {\n";
-        o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB);\n";
+        o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB, nxt_mem);\n";
         o << "      if (phase == 1u) pk++;\n";
         o << "    }\n";
         o << "    if (phase == 1u && pk == pp) {\n      // one period done: direction d = slots - saved slots; start the dual period from here\n";
@@ -377,12 +431,15 @@ struct Gen {
             o << "      { const uint32_t d = c." << words[k] << " - SA[" << k << " * 64]; SA[" << k << " * 64] = d; SD[" << k << " * 64] = d; SB[" << k
               << " * 64] = c." << words[k] << "; }\n";
         }
-        o << "      phase = 2u; pk = 0u; TBacc = (int64_t)1 << 40;\n    }\n";
+        o << "      phase = 2u; pk = 0u; TBacc = tb_init();\n    }\n";
         o << "    if (active) {\n      const bool done = accept || final_pass || !any_next;\n      i++;\n"
-             "      if (done) { results[sid] = accept ? 1 : 0; active = false; phase = 0u;\n";
+             "      st_steps++;\n      if (done) { results[sid] = accept ? 1 : 0; active = false; phase = 0u;\n"
+             "        if (stats && sid < (1u << 20)) ((uint32_t*)(stats + 8))[sid] = st_steps;\n        st_steps = 0;\n";
         for (const auto& w : words)
             if (w[0] == 'P') o << "        c." << w << " = MFA_EMPTY;\n";
-        o << "      }\n    }\n  }\n}\n";
+        o << "      }\n    }\n  }\n";
+        o << "  if (stats) {\n    if (lane == 0) { atomicAdd(&stats[0], st_iter); atomicAdd(&stats[1], st_dual); }\n"
+             "    atomicAdd(&stats[2], st_skip); atomicAdd(&stats[3], st_probe); atomicAdd(&stats[4], st_hit); atomicAdd(&stats[5], st_scan);\n  }\n}\n";
         (void)N;
         return o.str();
     }

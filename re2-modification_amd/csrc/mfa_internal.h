@@ -88,6 +88,7 @@ bool        jit_enabled(const HostImage& img);
 std::string jit_compile(const HostImage& img, std::string* err);
 bool        jit_load(const HostImage& img, DeviceState& ds);
 void        jit_unload(DeviceState& ds);
+void        jit_print_stats(DeviceState& ds, const char* tag);
 int         launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
                            void* stream);
 void device_release(DeviceState& ds);
