@@ -37,7 +37,7 @@ def load_blob(name):
         return image.blob_from_dump(f.read())
 
 
-def cpu_baseline(shards, budget_strings=3):
+def cpu_baseline(shards, gpu_results, budget_strings=3):
     """Time the reference itself (oracle/_ref/ref_harness: its own sources, built as it builds them, no
     -O flag, canonical allocation-order mode) on a bounded sample of the same workload; falls back to
     our CPU restatement when the reference build is not present."""
@@ -46,14 +46,16 @@ def cpu_baseline(shards, budget_strings=3):
     use_ref = os.path.exists(ref)
     if not use_ref and not os.path.exists(cli):
         return None
-    tot_bytes, tot_sec, n_str = 0, 0.0, 0
+    tot_bytes, tot_sec, n_str, acc_cpu, acc_gpu = 0, 0.0, 0, 0, 0
     with tempfile.TemporaryDirectory() as tmp:
         for ex, sh in shards.items():
             # the shortest-but-representative sample: first strings of the shard, capped in length so the
             # whole baseline stays within ~10-30 s (the reference is ~quadratic in string length)
-            sample = [s for s in sh["sample"] if len(s) <= 16384][:budget_strings]
+            idx = [k for k, s in enumerate(sh["sample"]) if len(s) <= 16384][:budget_strings]
+            sample = [sh["sample"][k] for k in idx]
             if not sample:
                 continue
+            acc_gpu += int(sum(int(gpu_results[ex][k]) for k in idx))
             text = b"".join(s + b"\n" for s in sample)
             if use_ref:
                 cmd = [ref, "time", "plain", corpus.EXAMPLES[ex][0]]
@@ -66,12 +68,14 @@ def cpu_baseline(shards, budget_strings=3):
             if p.returncode != 0:
                 return None
             f = p.stdout.split()
-            n_str += int(f[0]); tot_bytes += int(f[1]); tot_sec += float(f[2])
+            n_str += int(f[0]); tot_bytes += int(f[1]); tot_sec += float(f[2]); acc_cpu += int(f[3])
     if tot_sec <= 0:
         return None
     return {"value": tot_bytes / tot_sec / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference" if use_ref else "port",
             "sample": "%d strings (first <=%d of each example's shard with length <= 16 KiB), %d bytes, %.1f s, 1 thread" % (
-                n_str, budget_strings, tot_bytes, tot_sec)}
+                n_str, budget_strings, tot_bytes, tot_sec),
+            # the same strings were matched on the GPU in the timed region: the accept counts must agree
+            "accepted": acc_cpu, "accepted_gpu": acc_gpu, "parity": acc_cpu == acc_gpu}
 
 
 def secondary_dfa(device, n_strings=1 << 20, length=1024):
@@ -233,7 +237,11 @@ def main():
             "per_example": per_ex,
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(shards)
+            pos, gpu_res = 0, {}
+            for ex, sh in shards.items():
+                gpu_res[ex] = results[pos:pos + 16].cpu().numpy()
+                pos += sh["n"]
+            out["cpu_baseline"] = cpu_baseline(shards, gpu_res)
         if not args.no_secondary and world == 1:
             out["secondary"] = [secondary_dfa(device)]
         print(json.dumps(out))

@@ -165,6 +165,15 @@ struct Gen {
                 o << ind << "    const U " << vs << " = " << s.S[d] << ", " << vl << " = " << s.L[d] << "; const uint32_t " << vf << " = flagv("
                   << s.F[d] << ", TB);\n";
                 o << ind << "    " << s.F[d] << " = sel(" << rd << ", konst<U>(" << vf << " | F_READ), " << s.F[d] << ");\n";
+                o << ind << "    if (!REV) {                                       // run extent for one-byte-repeated values: found by the whole wave\n";
+                o << ind << "      const bool nr = " << rd << " && uni_needs_run(in, val(i), ch, val(" << vl << "), " << vf << ");\n";
+                o << ind << "      for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {\n";
+                o << ind << "        const int L = __builtin_ctzll(sb);\n";
+                o << ind << "        const uint32_t r = coop_period_end_fwd(in.bytes, ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L),\n";
+                o << ind << "                                               __shfl(in.len, L), __shfl(val(i), L), 1u, threadIdx.x & 63u);\n";
+                o << ind << "        if ((threadIdx.x & 63u) == (uint32_t)L) { in.run_lo = val(i); in.run_hi = r; in.run_ch = ch; }\n";
+                o << ind << "      }\n";
+                o << ind << "    }\n";
                 o << ind << "    bool " << ok << " = false, cmp" << id << " = false;\n";
                 o << ind << "    if (" << rd << ") " << ok << " = read_pre_u<REV, U>(in, i, ch, " << vs << ", " << vl << ", " << vf << ", TB, cmp" << id << ");\n";
                 o << ind << "    for (unsigned long long sb = __ballot(cmp" << id << "); sb; sb &= sb - 1ull) {      // byte-wise comparisons: one lane's at a time, whole wave\n";

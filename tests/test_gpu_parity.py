@@ -122,3 +122,59 @@ def test_long_runs_against_oracle(ex, mode):
     bad = np.nonzero(got != want)[0]
     assert bad.size == 0, "%s: %d mismatches, first len %d %r... want %d" % (
         name, bad.size, len(strings[bad[0]]), strings[bad[0]][:60], want[bad[0]])
+
+
+def _periodic_fuzz(rng, count, max_len, alphabet=b"abc"):
+    """Concatenations of periodic regions (period 1..8) with occasional single-byte damage: the inputs run /
+    period acceleration keys on, with region boundaries and damage at random phases."""
+    out = []
+    for _ in range(count):
+        s = bytearray()
+        target = int(rng.integers(40, max_len))
+        while len(s) < target:
+            q = int(rng.integers(1, 9))
+            word = bytes(rng.choice(list(alphabet), size=q, p=None).tolist())
+            reps = int(rng.integers(1, max(2, (target // q) // int(rng.integers(1, 4)) + 1)))
+            s += word * reps
+            if rng.random() < 0.3:
+                s += bytes([int(rng.choice(list(alphabet)))])
+        for _ in range(int(rng.integers(0, 3))):
+            s[int(rng.integers(0, len(s)))] = int(rng.choice(list(alphabet)))
+        out.append(bytes(s[:max_len]))
+    return out
+
+
+MFA_AUTOS = [a for a in MANIFEST["automata"] if not a["name"].startswith("nfa_")]
+
+
+@pytest.mark.parametrize("auto", MFA_AUTOS, ids=lambda a: a["name"])
+def test_periodic_fuzz_against_oracle(auto):
+    """Every memory automaton of the fixture set (plain, -bnf, -reverse images and the extra regexes, up to
+    three cells) on periodic inputs, against the CPU restatement."""
+    blob = image.blob_from_dump(oracle_lib.load_dump(auto["name"]))
+    rng = np.random.default_rng(int.from_bytes(auto["name"].encode(), "little") % (2 ** 32))
+    alphabet = b"abcd" if "d" in auto["regex"] else b"abc"
+    strings = _periodic_fuzz(rng, 128, 2500, alphabet)
+    want = oracle_lib.OracleImage(blob).match(strings)
+    got = gpu_match(capi.Image(blob), strings)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, "%s: %d mismatches, first len %d %r want %d" % (
+        auto["name"], bad.size, len(strings[bad[0]]), strings[bad[0]][:80], want[bad[0]])
+
+
+@pytest.mark.parametrize("ex", range(1, 11))
+def test_full_length_attack_strings(ex):
+    """BASELINE-size inputs (pump size 64 KiB, 40 000, 20 000 with a damaged byte) against the CPU
+    restatement: the strings the benchmark is made of, at the lengths where run acceleration does most work."""
+    from mfa_amd import corpus
+    regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+    rng = np.random.default_rng(77 + ex)
+    a = (prefix + corpus.pumped_string(65536, pump) + suffix).encode()
+    b = (prefix + corpus.pumped_string(40000, pump)).encode()
+    c = bytearray((prefix + corpus.pumped_string(20000, pump) + suffix).encode())
+    c[int(rng.integers(100, len(c) - 100))] = ord("b") if c[5000] != ord("b") else ord("a")
+    strings = [a, b, bytes(c)]
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex))
+    want = oracle_lib.OracleImage(blob).match(strings)
+    got = gpu_match(capi.Image(blob), strings)
+    assert list(got) == list(want)
