@@ -29,6 +29,7 @@ import torch  # noqa: E402
 from mfa_amd import capi, corpus, image, sharding  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PARITY_N = 48                  # strings per example whose GPU answers are re-checked on the CPU after the timed region
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
@@ -37,7 +38,7 @@ def load_blob(name):
         return image.blob_from_dump(f.read())
 
 
-def cpu_baseline(shards, gpu_results, budget_strings=3):
+def cpu_baseline(shards, gpu_results, budget_strings=8, cap=32768):
     """Time the reference itself (oracle/_ref/ref_harness: its own sources, built as it builds them, no
     -O flag, canonical allocation-order mode) on a bounded sample of the same workload; falls back to
     our CPU restatement when the reference build is not present."""
@@ -51,7 +52,7 @@ def cpu_baseline(shards, gpu_results, budget_strings=3):
         for ex, sh in shards.items():
             # the shortest-but-representative sample: first strings of the shard, capped in length so the
             # whole baseline stays within ~10-30 s (the reference is ~quadratic in string length)
-            idx = [k for k, s in enumerate(sh["sample"]) if len(s) <= 16384][:budget_strings]
+            idx = [k for k, s in enumerate(sh["sample"]) if len(s) <= cap][:budget_strings]
             sample = [sh["sample"][k] for k in idx]
             if not sample:
                 continue
@@ -69,13 +70,30 @@ def cpu_baseline(shards, gpu_results, budget_strings=3):
                 return None
             f = p.stdout.split()
             n_str += int(f[0]); tot_bytes += int(f[1]); tot_sec += float(f[2]); acc_cpu += int(f[3])
+        # wider parity check with the CPU restatement (fast): the first PARITY_N strings of every example
+        checked, mism = 0, 0
+        if os.path.exists(cli):
+            for ex, sh in shards.items():
+                sample = [s for s in sh["sample"] if len(s) <= 32768]
+                idx = [k for k, s in enumerate(sh["sample"]) if len(s) <= 32768]
+                blob_path = os.path.join(tmp, "p%d.blob" % ex)
+                with open(blob_path, "wb") as f:
+                    f.write(sh["blob"])
+                p = subprocess.run([cli, "match", blob_path], input=b"".join(s + b"\n" for s in sample), capture_output=True, cwd=tmp)
+                if p.returncode != 0:
+                    continue
+                want = [int(x) for x in p.stdout.split()]
+                got = [int(gpu_results[ex][k]) for k in idx]
+                checked += len(want)
+                mism += sum(1 for a, b in zip(want, got) if a != b) + abs(len(want) - len(got))
     if tot_sec <= 0:
         return None
     return {"value": tot_bytes / tot_sec / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference" if use_ref else "port",
-            "sample": "%d strings (first <=%d of each example's shard with length <= 16 KiB), %d bytes, %.1f s, 1 thread" % (
-                n_str, budget_strings, tot_bytes, tot_sec),
+            "sample": "%d strings (first <=%d of each example's shard with length <= %d KiB), %d bytes, %.1f s, 1 thread" % (
+                n_str, budget_strings, cap // 1024, tot_bytes, tot_sec),
             # the same strings were matched on the GPU in the timed region: the accept counts must agree
-            "accepted": acc_cpu, "accepted_gpu": acc_gpu, "parity": acc_cpu == acc_gpu}
+            "accepted": acc_cpu, "accepted_gpu": acc_gpu, "parity": acc_cpu == acc_gpu and mism == 0,
+            "parity_restatement": {"strings": checked, "mismatches": mism}}
 
 
 def secondary_dfa(device, n_strings=1 << 20, length=1024):
@@ -141,7 +159,7 @@ def main():
         img.prepare(local)
         nbytes = int(d_off[-1].item())
         shards[ex] = {"img": img, "bytes": d_bytes, "off": d_off, "n": n_per, "nbytes": nbytes, "blob": blob,
-                      "sample": corpus.host_strings(ex, sizes[:16], with_suffix[:16]) if rank == 0 else []}
+                      "sample": corpus.host_strings(ex, sizes[:PARITY_N], with_suffix[:PARITY_N]) if rank == 0 else []}
         total_bytes += nbytes
         total_strings += n_per
     results = torch.zeros(total_strings, dtype=torch.uint8, device=device)
@@ -239,7 +257,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             pos, gpu_res = 0, {}
             for ex, sh in shards.items():
-                gpu_res[ex] = results[pos:pos + 16].cpu().numpy()
+                gpu_res[ex] = results[pos:pos + PARITY_N].cpu().numpy()
                 pos += sh["n"]
             out["cpu_baseline"] = cpu_baseline(shards, gpu_res)
         if not args.no_secondary and world == 1:

@@ -350,7 +350,10 @@ struct Gen {
         o << "#if NEXT_IN_LDS\n  __shared__ uint32_t nxt_lds[2 * N_WORDS * 64];\n  uint32_t* const nxt_mem = nxt_lds + lane;\n#else\n  uint32_t* const nxt_mem = nullptr;\n#endif\n";
         o << "  // probe storage of this wave, [array][word][lane]: SA = slots at probe start, later the direction d;\n"
              "  // SB = slots at the start of the dual period; SD = direction carried between dual steps\n";
-        o << "  uint32_t* const SA = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u) + lane;\n";
+        // small automata keep it in LDS (3 x N_WORDS x 256 B per wave), larger ones in an L2-resident scratch buffer
+        const bool probe_lds = words.size() <= 32;
+        if (probe_lds) o << "  __shared__ uint32_t probe_lds[3 * N_WORDS * 64];\n  uint32_t* const SA = probe_lds + lane;\n  (void)scratch;\n";
+        else o << "  uint32_t* const SA = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u) + lane;\n";
         o << "  uint32_t* const SB = SA + N_WORDS * 64u;\n  uint32_t* const SD = SB + N_WORDS * 64u;\n";
         o << "  Input in; in.bytes = bytes; in.total16 = (offsets[n] + 15u) & ~(uint64_t)15; input_reset(in, 0, 0);\n";
         o << "  in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;\n";
