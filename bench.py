@@ -236,6 +236,17 @@ def main():
         for ex, sh in shards.items():
             per_ex[str(ex)]["accepted"] = int(results[pos:pos + sh["n"]].sum().item())
             pos += sh["n"]
+        # HBM traffic of one step from the PMC passes kept under profiles/ (collected separately: counters cannot be
+        # read from inside the run); only quoted when this run is the workload they were collected on
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01d_traffic.json")) as f:
+                tj = json.load(f)
+            wl = tj["workload"]
+            if (wl["strings_per_example"], wl["min_len"], wl["max_len"]) == (n_per, args.min_len, args.max_len) and args.concurrent:
+                traffic = tj["hbm_bytes_per_step"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "input GB/s (chars matched/sec) on 10-example attack corpus",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -247,7 +258,7 @@ def main():
                        "strings_per_gpu": total_strings, "bytes_per_gpu": total_bytes, "parallelism": "dp%d" % world,
                        "exchange": "gather of the result bitmap to rank 0" + (" (RCCL)" if dist else " (single rank: none)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "%s: 10 launches per step, one per example, %s" % (
                              "/".join(sorted({kinds[sh["img"].info()["last_kernel"]] for sh in shards.values()})),
                              "concurrent on 10 streams (duration = fork-to-join span)" if args.concurrent else "back to back on one stream"),

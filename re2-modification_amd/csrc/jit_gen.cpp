@@ -351,7 +351,7 @@ struct Gen {
         o << "  // probe storage of this wave, [array][word][lane]: SA = slots at probe start, later the direction d;\n"
              "  // SB = slots at the start of the dual period; SD = direction carried between dual steps\n";
         // small automata keep it in LDS (3 x N_WORDS x 256 B per wave), larger ones in an L2-resident scratch buffer
-        const bool probe_lds = words.size() <= 32;
+        const bool probe_lds = words.size() <= 64;      // 3 x 64 x 256 B = 48 KiB per wave at most
         if (probe_lds) o << "  __shared__ uint32_t probe_lds[3 * N_WORDS * 64];\n  uint32_t* const SA = probe_lds + lane;\n  (void)scratch;\n";
         else o << "  uint32_t* const SA = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u) + lane;\n";
         o << "  uint32_t* const SB = SA + N_WORDS * 64u;\n  uint32_t* const SD = SB + N_WORDS * 64u;\n";
