@@ -32,6 +32,7 @@
 // steps whose every branch outcome is proven, and any data-dependent comparison of string bytes inside
 // the step forces TB = 1.
 #include <cstdio>
+#include <cstdlib>
 #include <sstream>
 #include <string>
 
@@ -342,7 +343,9 @@ struct Gen {
         }
         emit_step();
         // ---- kernel
-        o << "extern \"C\" __global__ void __launch_bounds__(64)\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
+        // small automata: ask for two waves per SIMD (<= 128 VGPRs); the plain step needs far fewer, only the dual
+        // step is register hungry and may then spill a little -- it is rare
+        o << "extern \"C\" __global__ void __launch_bounds__(64" << (words.size() <= 20 ? ", 2" : "") << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
              "const uint64_t* __restrict__ offsets, uint64_t n,\n               uint8_t* __restrict__ results, "
              "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats) {\n";
         o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";
@@ -381,7 +384,8 @@ struct Gen {
         // decide whether this lane starts a probe: it must sit in a long run of equal bytes
         o << "    // does this lane sit at the start of a block that looks periodic?  then find how far the periodic region goes\n"
              "    uint32_t q = 0u;\n"
-             "    if (accel && active && !final_pass && phase == 0u && i >= probe_at) {\n"
+             "    const bool ep_busy = __any(phase != 0u);      // probes run in epochs: all lanes that probe do it in the same iterations\n"
+             "    if (accel && active && !final_pass && phase == 0u && i >= probe_at && !ep_busy) {\n"
              "      uint32_t rest;\n"
              "      q = block_period<REV>(in, i, rest);\n"
              "      probe_at = i + rest;                      // next look: first byte of the next block\n"
@@ -398,13 +402,17 @@ struct Gen {
              "        if (lane == (uint32_t)L) { in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++; }\n"
              "      }\n"
              "    }\n"
+             "    if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
+             "    if (q != 0u && q * mult > 16u) mult = 1u;\n"
+             "    const unsigned long long cand = __ballot(q != 0u && in.per_hi - i >= 4u * q * mult + 24u);\n"
+             "    const uint32_t ep_pp = cand ? __shfl(q * mult, __builtin_ctzll(cand)) : 0u;     // the first candidate's period leads the epoch\n"
              "    if (q != 0u) {\n"
-             "      if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
-             "      pp = q * mult;\n"
-             "      if (pp > 16u) { mult = 1u; pp = q; }\n"
-             "      if (in.per_hi - i >= 4u * pp + 24u) {\n";
+             "      pp = ep_pp;\n"
+             "      if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * pp + 24u) {\n";
         for (size_t k = 0; k < words.size(); k++) o << "        SA[" << k << " * 64] = c." << words[k] << ";\n";
-        o << "        phase = 1u; pk = 0u; st_probe++;\n      } else {\n        probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;\n      }\n    }\n";
+        o << "        phase = 1u; pk = 0u; st_probe++;\n      } else if (in.per_hi - i < 4u * q * mult + 24u) {\n"
+             "        probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // region too short to be worth a probe: look again behind it\n"
+             "      } else {\n        probe_at = i + 1u;                                       // does not fit this epoch's period: next epoch\n      }\n    }\n";
         o << "    bool any_next = false;\n    tb_t TB = tb_init();\n";
         o << "    if (__any(phase == 2u)) {\n";
         o << "      // dual step: lanes in phase 2 carry the direction saved in SD, the others d = 0 (their TB is ignored)\n";
@@ -427,11 +435,14 @@ struct Gen {
         o << "          phase = 0u;\n";
         o << "          if (skip) { backoff = 8u; fails = 0u; st_hit++; st_skip += (unsigned long long)skip * pp; }\n";
         o << "          else { fails++; mult = mult % 8u + 1u; if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; } }\n";
-        o << "        } else {\n";
+        o << "        } else if (tb_steps(TBacc) <= 1 || accept || !any_next) {\n"
+             "          phase = 0u; fails++; mult = mult % 8u + 1u;             // cannot succeed any more: stop the probe here\n"
+             "          if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
+             "        } else {\n";
         for (size_t k = 0; k < words.size(); k++) o << "          SD[" << k << " * 64] = (uint32_t)dc." << words[k] << ".d;\n";
         o << "        }\n      }\n";
         for (size_t k = 0; k < words.size(); k++) o << "      c." << words[k] << " = dc." << words[k] << ".v + skip * (uint32_t)dc." << words[k] << ".d;\n";
-        o << "      if (skip) { i += skip * pp; in.blk = ~(uint64_t)0; in.pblk = ~(uint64_t)0; probe_at = i + 2u; }\n";
+        o << "      if (skip) { i += skip * pp; in.blk = ~(uint64_t)0; in.pblk = ~(uint64_t)0; probe_at = i + 1u + pp; }\n";
         o << "      else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);\n";
         o << "      if (phase == 1u) pk++;\n";
         o << "    } else {\n";
