@@ -119,6 +119,62 @@ def secondary_dfa(device, n_strings=1 << 20, length=1024):
             "results_exact": ok}
 
 
+def _timed(img, flat, off, res, device, reps=3):
+    ms = []
+    for _ in range(reps + 1):
+        img.match_tensors(flat, off, res)
+        ms.append(img.last_kernel_ms(device.index or 0))
+    torch.cuda.synchronize()
+    return float(np.mean(ms[1:]))
+
+
+def secondary_config3(device, n_strings=1 << 17, length=65536):
+    """BASELINE.json configs[2] (roofline variant of SURVEY section 8d): example 1, strings of exactly 64 KiB, mix by
+    j mod 4: a^(L-1) b, a^L, a^L with one byte at a seeded position set to b, i.i.d. {a: 0.99, b: 0.01}."""
+    img = capi.Image(load_blob("ex1_plain"))
+    g = torch.Generator(device=device); g.manual_seed(0x5EED0003)
+    data = torch.full((n_strings, length), ord("a"), dtype=torch.uint8, device=device)
+    data[0::4, -1] = ord("b")
+    rows = torch.arange(2, n_strings, 4, device=device)
+    data[rows, torch.randint(0, length, (rows.numel(),), generator=g, device=device)] = ord("b")
+    for lo in range(3, n_strings, 4 * 4096):                      # the random rows, in chunks
+        r = torch.arange(lo, min(n_strings, lo + 4 * 4096), 4, device=device)
+        mask = torch.rand((r.numel(), length), generator=g, device=device) < 0.01
+        data[r] = torch.where(mask, torch.tensor(ord("b"), dtype=torch.uint8, device=device), data[r])
+        del mask
+    flat = torch.cat([data.reshape(-1), torch.zeros(64, dtype=torch.uint8, device=device)])
+    del data
+    off = torch.arange(0, (n_strings + 1) * length, length, dtype=torch.int64, device=device)
+    res = torch.empty(n_strings, dtype=torch.uint8, device=device)
+    t = _timed(img, flat, off, res, device)
+    gbs = n_strings * length / (t * 1e-3) / 1e9
+    # a^L is accepted (SURVEY section 8c anchors: aa, aaa, aaaa, aaaaaaaa -> 1), every string containing a b is not
+    ok = bool(res[1::4].all().item()) and not bool(res[0::4].any().item()) and not bool(res[2::4].any().item())
+    return {"workload": "configs[2]: ({a*}:1&1)*, %d strings of exactly %d bytes, 4-way attack mix" % (n_strings, length),
+            "kernel": "mfa_jit_kernel", "kernel_ms": t, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "results_as_expected": ok}
+
+
+def secondary_config5(device, n_strings=125000):
+    """BASELINE.json configs[4]: reversed MFAs (`-reverse`, is_reversed = 1) of the nondeterministic examples 3, 6, 8 on
+    pump-only strings (full walk) and pump+suffix strings (early exit), reported separately.  Images are the reference's
+    own `-reverse` automata (tests/golden/images): this build's front-end has no BNF rewriter yet."""
+    out = []
+    for ex in (3, 6, 8):
+        img = capi.Image(load_blob("ex%d_reverse" % ex))
+        n = n_strings if ex != 8 else n_strings // 50            # ex. 8 -reverse has 77 nodes: table-driven kernel, no acceleration
+        for tag, suffix in (("pump only", False), ("pump + suffix", True)):
+            sizes = corpus.pump_sizes(n, 0x5EED0005 + ex, 1024, 65536)
+            flat, off = corpus.device_batch(ex, sizes, np.full(n, suffix), device)
+            res = torch.empty(n, dtype=torch.uint8, device=device)
+            t = _timed(img, flat, off, res, device, reps=2)
+            nbytes = int(off[-1].item())
+            out.append({"workload": "configs[4]: example %d -reverse, %d strings, %s" % (ex, n, tag),
+                        "kernel": {capi.KERNEL_GENERIC: "mfa_walk_kernel", capi.KERNEL_SPECIALISED: "mfa_jit_kernel"}[img.info()["last_kernel"]],
+                        "kernel_ms": t, "GB/s": nbytes / (t * 1e-3) / 1e9, "accepted": int(res.sum().item())})
+            del flat, off, res
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,7 +328,10 @@ def main():
                 pos += sh["n"]
             out["cpu_baseline"] = cpu_baseline(shards, gpu_res)
         if not args.no_secondary and world == 1:
-            out["secondary"] = [secondary_dfa(device)]
+            for sh in shards.values():                   # free the headline shard before the other configurations
+                sh["bytes"] = sh["off"] = None
+            torch.cuda.empty_cache()
+            out["secondary"] = [secondary_dfa(device), secondary_config3(device)] + secondary_config5(device)
         print(json.dumps(out))
     if dist:
         dist.barrier()
