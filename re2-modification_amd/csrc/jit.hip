@@ -56,7 +56,7 @@ static std::string image_key(const HostImage& img) {
 bool jit_enabled(const HostImage& img) {
     const char* e = getenv("MFA_JIT");
     if (e && e[0] == '0') return false;
-    return img.h.kind == MFA_KIND_MFA && jit_slot_registers(img) <= 224;
+    return img.h.kind == MFA_KIND_MFA && jit_slot_registers(img) <= 272;     // two slot sets in the 512-entry VGPR+AGPR file, one wave per SIMD
 }
 
 static bool file_exists(const std::string& p) {

@@ -345,7 +345,7 @@ struct Gen {
         // ---- kernel
         // small automata: ask for two waves per SIMD (<= 128 VGPRs); the plain step needs far fewer, only the dual
         // step is register hungry and may then spill a little -- it is rare
-        o << "extern \"C\" __global__ void __launch_bounds__(64" << (words.size() <= 20 ? ", 2" : "") << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
+        o << "extern \"C\" __global__ void __launch_bounds__(64" << (getenv("MFA_GEN_W2_ALL") ? ", 2" : (words.size() <= 20 ? ", 2" : "")) << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
              "const uint64_t* __restrict__ offsets, uint64_t n,\n               uint8_t* __restrict__ results, "
              "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats) {\n";
         o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";
