@@ -166,11 +166,11 @@ struct Gen {
                 o << ind << "    const U " << vs << " = " << s.S[d] << ", " << vl << " = " << s.L[d] << "; const uint32_t " << vf << " = flagv("
                   << s.F[d] << ", TB);\n";
                 o << ind << "    " << s.F[d] << " = sel(" << rd << ", konst<U>(" << vf << " | F_READ), " << s.F[d] << ");\n";
-                o << ind << "    if (!REV) {                                       // run extent for one-byte-repeated values: found by the whole wave\n";
+                o << ind << "    {                                                  // run extent for one-byte-repeated values: found by the whole wave\n";
                 o << ind << "      const bool nr = " << rd << " && uni_needs_run(in, val(i), ch, val(" << vl << "), " << vf << ");\n";
                 o << ind << "      for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {\n";
                 o << ind << "        const int L = __builtin_ctzll(sb);\n";
-                o << ind << "        const uint32_t r = coop_period_end_fwd(in.bytes, ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L),\n";
+                o << ind << "        const uint32_t r = coop_period_end<REV>(in.bytes, ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L),\n";
                 o << ind << "                                               __shfl(in.len, L), __shfl(val(i), L), 1u, threadIdx.x & 63u);\n";
                 o << ind << "        if ((threadIdx.x & 63u) == (uint32_t)L) { in.run_lo = val(i); in.run_hi = r; in.run_ch = ch; }\n";
                 o << ind << "      }\n";
@@ -392,15 +392,11 @@ struct Gen {
              "      if (rest < 8u) q = 0u;\n"
              "    }\n"
              "    bool need_scan = q != 0u && !(in.per_q == q && in.per_lo <= i && i < in.per_hi);\n"
-             "    if (REV) {\n"
-             "      if (need_scan) { in.per_hi = q == 1u ? run_end_from<REV>(in, i, ch) : period_end_from<REV>(in, i, q); in.per_lo = i; in.per_q = q; st_scan++; }\n"
-             "    } else {\n"
-             "      for (unsigned long long sb = __ballot(need_scan); sb; sb &= sb - 1ull) {          // one string at a time, all lanes scanning\n"
-             "        const int L = __builtin_ctzll(sb);\n"
-             "        const uint64_t sbase = ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L);\n"
-             "        const uint32_t r = coop_period_end_fwd(bytes, sbase, __shfl(len, L), __shfl(i, L), __shfl(q, L), lane);\n"
-             "        if (lane == (uint32_t)L) { in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++; }\n"
-             "      }\n"
+             "    for (unsigned long long sb = __ballot(need_scan); sb; sb &= sb - 1ull) {          // one string at a time, all lanes scanning\n"
+             "      const int L = __builtin_ctzll(sb);\n"
+             "      const uint64_t sbase = ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L);\n"
+             "      const uint32_t r = coop_period_end<REV>(bytes, sbase, __shfl(len, L), __shfl(i, L), __shfl(q, L), lane);\n"
+             "      if (lane == (uint32_t)L) { in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++; }\n"
              "    }\n"
              "    if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
              "    if (q != 0u && q * mult > 16u) mult = 1u;\n"
