@@ -84,18 +84,6 @@ __device__ __forceinline__ uint32_t mismatch_mask16(uint4 d, uint32_t c) {
     return nz4(d.x ^ cc) | (nz4(d.y ^ cc) << 4) | (nz4(d.z ^ cc) << 8) | (nz4(d.w ^ cc) << 12);
 }
 
-// Register-only test on the 16-byte block stream_byte holds: are the bytes from scan index i to the end
-// of the block (in scan direction) all equal to c?  `rest` = how many bytes that is.  Used to decide
-// whether looking for a long run is worth a scan of memory.
-template <bool REV>
-__device__ __forceinline__ bool block_rest_uniform(const Input& in, uint32_t i, uint32_t c, uint32_t& rest) {
-    const uint32_t o = (uint32_t)scan_addr<REV>(in, i) & 15u;
-    uint32_t m = mismatch_mask16(make_uint4(in.w0, in.w1, in.w2, in.w3), c);
-    m &= REV ? ((2u << o) - 1u) : (0xffffu << o);
-    rest = REV ? o + 1u : 16u - o;
-    return m == 0u;
-}
-
 // Register-only: smallest q in 1..8 such that the bytes of the current block from scan index i to the
 // end of the block (in scan direction) are q-periodic, with at least two periods visible; 0 if none.
 template <bool REV>
@@ -119,44 +107,6 @@ __device__ __forceinline__ uint32_t block_period(const Input& in, uint32_t i, ui
         if ((dlo | dhi) == 0) return q;
     }
     return 0u;
-}
-
-// exclusive end R (scan index) of the q-periodic region that starts at scan index i:
-// scan[j] == scan[j + q] for i <= j < R - q, and R is maximal
-template <bool REV>
-__device__ __forceinline__ uint32_t period_end_from(const Input& in, uint32_t i, uint32_t q) {
-    if (i + q >= in.len) return in.len;
-    if (!REV) {
-        const uint8_t* p = in.bytes + in.base;
-        uint32_t j = i;
-        const uint32_t last = in.len - q;                // compare j with j+q while j < last
-        while (j + 32u <= last) {
-            uint64_t x[4], y[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { __builtin_memcpy(&x[k], p + j + 8 * k, 8); __builtin_memcpy(&y[k], p + j + q + 8 * k, 8); }
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (x[k] != y[k]) return j + 8u * k + ((uint32_t)__builtin_ctzll(x[k] ^ y[k]) >> 3) + q;
-            j += 32u;
-        }
-        for (; j < last; j++)
-            if (p[j] != p[j + q]) return j + q;
-        return in.len;
-    }
-    // reversed scan: scan index j lives at address base + len - 1 - j
-    const uint8_t* top = in.bytes + in.base + in.len - 1u;
-    uint32_t j = i;
-    const uint32_t last = in.len - q;
-    while (j + 8u <= last) {
-        uint64_t x, y;                                   // bytes at scan indices j..j+7 are top-j-7 .. top-j ascending
-        __builtin_memcpy(&x, top - j - 7, 8);
-        __builtin_memcpy(&y, top - j - q - 7, 8);
-        if (x != y) return j + ((uint32_t)__builtin_clzll(x ^ y) >> 3) + q;
-        j += 8u;
-    }
-    for (; j < last; j++)
-        if (*(top - j) != *(top - j - q)) return j + q;
-    return in.len;
 }
 
 // smallest offset q in [p, e) with bytes[q] != c, or e
@@ -495,25 +445,6 @@ __device__ __forceinline__ void spans_period_bound(const Input& in, Dual i, Dual
     if (!ok) { tb_min(TB, 1); return; }
     (void)le(add(i, l), Dual{in.per_hi, 0}, TB);         // both sides stay inside the periodic region: same bytes every period
     if (start.d != 0) (void)le(add(start, l), Dual{in.per_hi, 0}, TB);
-}
-
-template <bool REV, class U>
-__device__ __forceinline__ bool read_matches_u(Input& in, U i, uint32_t ch, U start, U l, uint32_t fl, tb_t& TB) {
-    if (lt(sub(konst<U>(in.len), i), l, TB)) return false;
-    if (eq(l, konst<U>(0u), TB)) return true;
-    if (fl & F_UNI) {
-        const uint32_t c = (fl >> 8) & 0xffu;
-        if (c != ch) return false;
-        if (eq(l, konst<U>(1u), TB)) return true;
-        const uint32_t iv = val(i);
-        if (!(in.run_ch == c && in.run_lo <= iv && iv < in.run_hi)) {
-            in.run_hi = run_end_from<REV>(in, iv, c);
-            in.run_lo = iv; in.run_ch = c;
-        }
-        return ge(sub(run_hi_u(in, i, TB), i), l, TB);
-    }
-    spans_period_bound(in, i, start, l, TB);
-    return spans_equal<REV>(in, val(start), val(i), val(l));
 }
 
 // would the cell read below have to look for the end of the run of bytes at i?  (then the caller finds it

@@ -32,7 +32,6 @@
 // steps whose every branch outcome is proven, and any data-dependent comparison of string bytes inside
 // the step forces TB = 1.
 #include <cstdio>
-#include <cstdlib>
 #include <sstream>
 #include <string>
 
@@ -92,6 +91,7 @@ struct Gen {
         std::string w = "w" + num(tmp++), pv = "p" + num(tmp++);
         o << ind << "{ const U " << pv << " = " << P << ";\n";
         o << ind << "  const bool " << w << " = (" << pred << ") && lt(" << pv << ", n.P" << m << ", TB);\n";
+        o << ind << "  if (!NextSet<U>::in_lds || __any(" << w << ")) {       // a next set in LDS is only touched when some lane wins\n";
         o << ind << "  n.P" << m << " = sel(" << w << ", " << pv << ", n.P" << m << ");\n";
         for (int c = 0; c < K; c++) {
             std::string sfx = num(m) + "_" + num(c);
@@ -99,7 +99,7 @@ struct Gen {
             o << " n.L" << sfx << " = sel(" << w << ", " << t.L[c] << ", n.L" << sfx << ");";
             o << " n.F" << sfx << " = sel(" << w << ", " << t.F[c] << ", n.F" << sfx << ");\n";
         }
-        o << ind << "}\n";
+        o << ind << "  }\n" << ind << "}\n";
     }
 
     // declare a copy of `s` as fresh variables; returns the new symbolic state
@@ -329,23 +329,23 @@ struct Gen {
         o << "template <class U> struct NextSet;\n";
         o << "template <> struct NextSet<uint32_t> {\n";
         for (const auto& w : words) o << "  uint32_t " << w << ";\n";
-        o << "  __device__ __forceinline__ explicit NextSet(uint32_t*) {}\n};\n";
+        o << "  static constexpr bool in_lds = false;\n  __device__ __forceinline__ explicit NextSet(uint32_t*) {}\n};\n";
         if (lds_next) {
             o << "template <> struct NextSet<Dual> {\n";
             for (const auto& w : words) o << "  LdsDual " << w << ";\n";
-            o << "  __device__ __forceinline__ explicit NextSet(uint32_t* m) :";
+            o << "  static constexpr bool in_lds = true;\n  __device__ __forceinline__ explicit NextSet(uint32_t* m) :";
             for (size_t k = 0; k < words.size(); k++) o << (k ? ", " : " ") << words[k] << "{m + " << 2 * k << " * 64}";
             o << " {}\n};\n\n";
         } else {
             o << "template <> struct NextSet<Dual> {\n";
             for (const auto& w : words) o << "  Dual " << w << ";\n";
-            o << "  __device__ __forceinline__ explicit NextSet(uint32_t*) {}\n};\n\n";
+            o << "  static constexpr bool in_lds = false;\n  __device__ __forceinline__ explicit NextSet(uint32_t*) {}\n};\n\n";
         }
         emit_step();
         // ---- kernel
         // small automata: ask for two waves per SIMD (<= 128 VGPRs); the plain step needs far fewer, only the dual
         // step is register hungry and may then spill a little -- it is rare
-        o << "extern \"C\" __global__ void __launch_bounds__(64" << (getenv("MFA_GEN_W2_ALL") ? ", 2" : (words.size() <= 20 ? ", 2" : "")) << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
+        o << "extern \"C\" __global__ void __launch_bounds__(64" << (words.size() <= 20 ? ", 2" : "") << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
              "const uint64_t* __restrict__ offsets, uint64_t n,\n               uint8_t* __restrict__ results, "
              "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats) {\n";
         o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";

@@ -12,8 +12,6 @@
 
 #include "../../include/mfa_hip.h"
 
-struct hipStreamWrap;  // opaque
-
 namespace mfa {
 
 // ---- host image ---------------------------------------------------------------------------
