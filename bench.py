@@ -193,13 +193,21 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MFA_BENCH_REHEARSE=1: N ranks on ONE GPU with the gloo backend (bitmaps gathered through host memory) -- only to
+    # exercise the N > 1 code path on a single-GPU box; real runs use one GPU per rank and RCCL
+    rehearse = os.environ.get("MFA_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     # ---- this rank's shard, resident in HBM ---------------------------------------------------------
     shards = {}
@@ -220,7 +228,8 @@ def main():
         total_strings += n_per
     results = torch.zeros(total_strings, dtype=torch.uint8, device=device)
     n_bitmap = (total_strings + 7) // 8
-    gathered = [torch.empty(n_bitmap, dtype=torch.uint8, device=device) for _ in range(world)] if (dist and rank == 0) else None
+    comm_dev = torch.device("cpu") if rehearse else device
+    gathered = [torch.empty(n_bitmap, dtype=torch.uint8, device=comm_dev) for _ in range(world)] if (dist and rank == 0) else None
     kernel_ms = {ex: [] for ex in shards}
     span_ms = []
     # one HIP stream per example: the ten launches of a step are independent, so they run concurrently and
@@ -246,7 +255,7 @@ def main():
         ev_join.record(main)
         bitmap = sharding.pack_bitmap(results)
         if dist:
-            dist.gather(bitmap, gathered, dst=0)      # RCCL over xGMI: the path's only exchange
+            dist.gather(bitmap.to(comm_dev), gathered, dst=0)      # RCCL over xGMI: the path's only exchange
         if record:
             for ex, sh in shards.items():
                 kernel_ms[ex].append(sh["img"].last_kernel_ms(local))
@@ -269,7 +278,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

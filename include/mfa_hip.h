@@ -89,6 +89,7 @@ int  mfa_image_specialize(mfa_image_t* img);
 /* Match n strings; string k is bytes[offsets[k] .. offsets[k+1]).  ALL pointers are
  * DEVICE pointers on `device` (offsets has n+1 entries; results gets n bytes, 1 =
  * accepted, 0 = rejected -- the value `cout << match` prints, match.cpp:30).
+ * A string longer than MFA_MAX_STRING_BYTES is not matched: its result byte is set to 2.
  * Asynchronous: work is enqueued on `stream` (a hipStream_t, NULL = default
  * stream) and the call returns.  Replaces: the loop
  *     while (...) { match = automata->match(text); }      match.cpp:21-31 */
