@@ -161,7 +161,7 @@ def secondary_config5(device, n_strings=125000):
     out = []
     for ex in (3, 6, 8):
         img = capi.Image(load_blob("ex%d_reverse" % ex))
-        n = n_strings if ex != 8 else n_strings // 50            # ex. 8 -reverse has 77 nodes: table-driven kernel, no acceleration
+        n = n_strings if ex != 8 else n_strings // 5             # ex. 8 -reverse has 77 nodes: slot sets in LDS, 16 strings per wave
         for tag, suffix in (("pump only", False), ("pump + suffix", True)):
             sizes = corpus.pump_sizes(n, 0x5EED0005 + ex, 1024, 65536)
             flat, off = corpus.device_batch(ex, sizes, np.full(n, suffix), device)

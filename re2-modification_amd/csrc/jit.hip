@@ -23,7 +23,7 @@ extern char** environ;
 
 namespace mfa {
 
-static const char* kGeneratorVersion = "jit-28";
+static const char* kGeneratorVersion = "jit-30";
 
 static std::string cache_dir() {
     if (const char* e = getenv("MFA_JIT_CACHE")) return e;
@@ -56,7 +56,7 @@ static std::string image_key(const HostImage& img) {
 bool jit_enabled(const HostImage& img) {
     const char* e = getenv("MFA_JIT");
     if (e && e[0] == '0') return false;
-    return img.h.kind == MFA_KIND_MFA && jit_slot_registers(img) <= 272;     // two slot sets in the 512-entry VGPR+AGPR file, one wave per SIMD
+    return img.h.kind == MFA_KIND_MFA && jit_lanes(img) != 0;      // up to 272 slot registers in VGPRs, beyond that slot sets in LDS
 }
 
 static bool file_exists(const std::string& p) {
@@ -122,6 +122,7 @@ bool jit_load(const HostImage& img, DeviceState& ds) {
     if (hipModuleOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fn, 64, 0) != hipSuccess || blocks <= 0) blocks = 4;
     ds.jit_mod = mod; ds.jit_fn = fn; ds.jit_waves_per_cu = blocks > 32 ? 32 : blocks;
     ds.jit_words = jit_slot_registers(img) / 2;
+    ds.jit_lanes = jit_lanes(img);
     return true;
 }
 
@@ -130,7 +131,7 @@ int launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_of
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(ds.d_counter, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
-    uint64_t grid = (uint64_t)ds.n_cus * ds.jit_waves_per_cu, want = (n + 63) / 64;
+    uint64_t grid = (uint64_t)ds.n_cus * ds.jit_waves_per_cu, want = (n + ds.jit_lanes - 1) / ds.jit_lanes;
     if (grid > want) grid = want;
     if (grid == 0) grid = 1;
     const char* ae = getenv("MFA_ACCEL");

@@ -45,6 +45,16 @@ const char* kPrelude =
 #include "device_common.inc"
     ;
 
+// Automata whose two slot sets do not fit the register file ("huge": > 272 slot registers) keep every slot set
+// in LDS and let fewer lanes of the wave carry strings, as many as one CU's 160 KiB allow for the seven images
+// a dual step and its probe need (current and next set with directions, three probe images), plus one column
+// that the idle lanes scribble on.  The idle lanes still take part in the cooperative scans.
+static uint32_t huge_lanes(uint32_t n_words) {
+    for (uint32_t lanes : {32u, 16u, 8u})
+        if ((size_t)7 * n_words * (lanes + 1) * 4 <= 156 * 1024) return lanes;
+    return 0;
+}
+
 struct Gen {
     const HostImage& g;
     std::ostringstream o;
@@ -64,7 +74,7 @@ struct Gen {
     // a symbolic state: names of the variables (type U) that hold it; known[c]: cell c is statically present
     struct Sym { std::string pos; std::vector<std::string> S, L, F; std::vector<bool> known; };
 
-    std::string present(const Sym& s, int c) { return "(flagv(" + s.F[c] + ", TB) & F_PRESENT)"; }
+    std::string present(const Sym& s, int c) { return "(flagv(U(" + s.F[c] + "), TB) & F_PRESENT)"; }
 
     std::string fname(const Sym& s) {          // plain uint32_t expression
         std::string e = "0u";
@@ -90,14 +100,14 @@ struct Gen {
     void insert(uint32_t m, const std::string& pred, const std::string& P, const Sym& t, const std::string& ind) {
         std::string w = "w" + num(tmp++), pv = "p" + num(tmp++);
         o << ind << "{ const U " << pv << " = " << P << ";\n";
-        o << ind << "  const bool " << w << " = (" << pred << ") && lt(" << pv << ", n.P" << m << ", TB);\n";
+        o << ind << "  const bool " << w << " = (" << pred << ") && lt(" << pv << ", U(n.P" << m << "), TB);\n";
         o << ind << "  if (!NextSet<U>::in_lds || __any(" << w << ")) {       // a next set in LDS is only touched when some lane wins\n";
-        o << ind << "  n.P" << m << " = sel(" << w << ", " << pv << ", n.P" << m << ");\n";
+        o << ind << "  n.P" << m << " = sel(" << w << ", " << pv << ", U(n.P" << m << "));\n";
         for (int c = 0; c < K; c++) {
             std::string sfx = num(m) + "_" + num(c);
-            o << ind << "  n.S" << sfx << " = sel(" << w << ", " << t.S[c] << ", n.S" << sfx << ");";
-            o << " n.L" << sfx << " = sel(" << w << ", " << t.L[c] << ", n.L" << sfx << ");";
-            o << " n.F" << sfx << " = sel(" << w << ", " << t.F[c] << ", n.F" << sfx << ");\n";
+            o << ind << "  n.S" << sfx << " = sel(" << w << ", U(" << t.S[c] << "), U(n.S" << sfx << "));";
+            o << " n.L" << sfx << " = sel(" << w << ", U(" << t.L[c] << "), U(n.L" << sfx << "));";
+            o << " n.F" << sfx << " = sel(" << w << ", U(" << t.F[c] << "), U(n.F" << sfx << "));\n";
         }
         o << ind << "  }\n" << ind << "}\n";
     }
@@ -110,7 +120,7 @@ struct Gen {
             t.S[c] = "tS" + num(id) + "_" + num(c);
             t.L[c] = "tL" + num(id) + "_" + num(c);
             t.F[c] = "tF" + num(id) + "_" + num(c);
-            o << ind << "U " << t.S[c] << " = " << s.S[c] << ", " << t.L[c] << " = " << s.L[c] << ", " << t.F[c] << " = " << s.F[c] << ";\n";
+            o << ind << "U " << t.S[c] << " = U(" << s.S[c] << "), " << t.L[c] << " = U(" << s.L[c] << "), " << t.F[c] << " = U(" << s.F[c] << ");\n";
         }
         return t;
     }
@@ -163,9 +173,9 @@ struct Gen {
                 Sym t = copy_of(s, ind + "    ");                      // copy BEFORE read() marks the source (mfa.cpp:167/177)
                 std::string id = num(tmp++);
                 std::string vs = "vs" + id, vl = "vl" + id, vf = "vf" + id, ok = "k" + id;
-                o << ind << "    const U " << vs << " = " << s.S[d] << ", " << vl << " = " << s.L[d] << "; const uint32_t " << vf << " = flagv("
-                  << s.F[d] << ", TB);\n";
-                o << ind << "    " << s.F[d] << " = sel(" << rd << ", konst<U>(" << vf << " | F_READ), " << s.F[d] << ");\n";
+                o << ind << "    const U " << vs << " = U(" << s.S[d] << "), " << vl << " = U(" << s.L[d] << "); const uint32_t " << vf << " = flagv(U("
+                  << s.F[d] << "), TB);\n";
+                o << ind << "    " << s.F[d] << " = sel(" << rd << ", konst<U>(" << vf << " | F_READ), U(" << s.F[d] << "));\n";
                 o << ind << "    {                                                  // run extent for one-byte-repeated values: found by the whole wave\n";
                 o << ind << "      const bool nr = " << rd << " && uni_needs_run(in, val(i), ch, val(" << vl << "), " << vf << ");\n";
                 o << ind << "      for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {\n";
@@ -240,72 +250,130 @@ struct Gen {
         return w;
     }
 
+    // ---- pieces of one step -----------------------------------------------------------------------------
+    void emit_classify(uint32_t n) {                      // pos / live / here / wait of slot n
+        std::string s = num(n);
+        o << "  const U pos" << s << " = posof(U(c.P" << s << "), TB);\n";
+        o << "  bool live" << s << " = active && ne(U(c.P" << s << "), konst<U>(MFA_EMPTY), TB) && ge(pos" << s << ", i, TB);\n";
+        if (rev) {                                               // mfa.cpp:116-133
+            o << "  if (live" << s << ") { U need = konst<U>(0u);";
+            for (int c = 0; c < K; c++) {
+                std::string f = "flagv(U(c.F" + s + "_" + num(c) + "), TB)";
+                o << " if ((" << f << " & F_PRESENT) && ((" << f << " & F_OPEN) || !(" << f << " & F_READ))) need = add(need, U(c.L" << s << "_" << c << "));";
+            }
+            o << " live" << s << " = le(need, sub(len, i), TB); }\n";
+        }
+        o << "  const bool here" << s << " = live" << s << " && !final_pass && eq(pos" << s << ", i, TB);\n";
+        o << "  const bool wait" << s << " = live" << s << " && !final_pass && !here" << s << ";\n";
+        o << "  (void)wait" << s << ";\n";
+    }
+
+    void emit_phase_a(uint32_t n) {                       // epsilon acceptance of the slot state, waiting states carry over
+        Sym s = cur_sym(n, "c.");
+        bool has_eps = false;
+        for (uint32_t k = 0; k < deg(n); k++) has_eps = has_eps || eps(edge(n, k));
+        if (has_eps) o << "  accept = accept || (live" << n << " && eq(pos" << n << ", len, TB));\n";
+        std::string q = qualifies(n, s);
+        o << "  n.P" << n << " = sel(wait" << n << " && " << q << ", U(c.P" << n << "), konst<U>(MFA_EMPTY));";
+        for (int c = 0; c < K; c++) {
+            std::string sfx = num(n) + "_" + num(c);
+            o << " n.S" << sfx << " = U(c.S" << sfx << "); n.L" << sfx << " = U(c.L" << sfx << "); n.F" << sfx << " = U(c.F" << sfx << ");";
+        }
+        o << "\n";
+    }
+
+    void emit_phase_b(uint32_t n) {                       // the state at pos == i consumes
+        o << "  if (__any(here" << n << ")) {   // node " << n << "\n";
+        Sym s = cur_sym(n, "c.");
+        edges(n, s, "here" + num(n), 0, true, "    ");
+        o << "  }\n";
+    }
+
+    bool has_phase_c(uint32_t n) {
+        for (uint32_t k = 0; k < deg(n); k++)
+            if (digit(edge(n, k)) >= 0 && !is_finish(edge(n, k).target)) return true;
+        return false;
+    }
+
+    void emit_phase_c(uint32_t n) {                       // unset-cell edges of waiting states (and of pos == len states in the final pass)
+        o << "  { const bool late" << n << " = live" << n << " && !here" << n << ";\n";
+        o << "    if (__any(late" << n << ")) {\n";
+        Sym s = cur_sym(n, "c.");
+        for (uint32_t k = 0; k < deg(n); k++) {
+            const auto& e = edge(n, k);
+            if (eps(e) || digit(e) < 0 || is_finish(e.target)) continue;        // epsilon acceptance of the slot state: phase A
+            unset_cell(e, s, "late" + num(n), 0, false, "      ");
+        }
+        o << "    }\n  }\n";
+    }
+
+    void emit_end() {
+        o << "  any_next = false;\n";
+        for (uint32_t n = 0; n < g.h.n_nodes; n++)
+            if (!is_finish(n)) o << "  any_next = any_next || ne(U(n.P" << n << "), konst<U>(MFA_EMPTY), TB);\n";
+        for (const auto& w : slot_words()) o << "  c." << w << " = U(n." << w << ");\n";
+    }
+
+    // One step as a single inlined function: slot sets are registers, everything stays in one scope.
     void emit_step() {
         const uint32_t N = g.h.n_nodes;
         o << "template <class U>\n__device__ __forceinline__ void mfa_step(SlotSet<U>& c, Input& in, const U i, const U len, const uint32_t ch,\n"
-             "                                         const bool final_pass, bool& accept, bool& any_next, tb_t& TB, uint32_t* nxt_mem) {\n";
-        o << "  NextSet<U> n(nxt_mem);\n";
-        // ---- classify the current slots
-        for (uint32_t n = 0; n < N; n++) {
-            if (is_finish(n)) continue;
-            std::string s = num(n);
-            o << "  const U pos" << s << " = posof(c.P" << s << ", TB);\n";
-            o << "  bool live" << s << " = ne(c.P" << s << ", konst<U>(MFA_EMPTY), TB) && ge(pos" << s << ", i, TB);\n";
-            if (rev) {                                               // mfa.cpp:116-133
-                o << "  if (live" << s << ") { U need = konst<U>(0u);";
-                for (int c = 0; c < K; c++) {
-                    std::string f = "flagv(c.F" + s + "_" + num(c) + ", TB)";
-                    o << " if ((" << f << " & F_PRESENT) && ((" << f << " & F_OPEN) || !(" << f << " & F_READ))) need = add(need, c.L" << s << "_" << c << ");";
-                }
-                o << " live" << s << " = le(need, sub(len, i), TB); }\n";
-            }
-            o << "  const bool here" << s << " = live" << s << " && !final_pass && eq(pos" << s << ", i, TB);\n";
-            o << "  const bool wait" << s << " = live" << s << " && !final_pass && !here" << s << ";\n";
-        }
-        // ---- phase A: epsilon acceptance of the slot states themselves, waiting states carry over
-        for (uint32_t n = 0; n < N; n++) {
-            if (is_finish(n)) continue;
-            Sym s = cur_sym(n, "c.");
-            bool has_eps = false;
-            for (uint32_t k = 0; k < deg(n); k++) has_eps = has_eps || eps(edge(n, k));
-            if (has_eps) o << "  accept = accept || (live" << n << " && eq(pos" << n << ", len, TB));\n";
-            std::string q = qualifies(n, s);
-            o << "  n.P" << n << " = sel(wait" << n << " && " << q << ", c.P" << n << ", konst<U>(MFA_EMPTY));";
-            for (int c = 0; c < K; c++) {
-                std::string sfx = num(n) + "_" + num(c);
-                o << " n.S" << sfx << " = c.S" << sfx << "; n.L" << sfx << " = c.L" << sfx << "; n.F" << sfx << " = c.F" << sfx << ";";
-            }
-            o << "\n";
-        }
-        // ---- phase B: states at pos == i, in node order
+             "                                         const bool final_pass, bool& accept, bool& any_next, tb_t& TB, uint32_t* cur_mem,\n"
+             "                                         uint32_t* nxt_mem, const bool active) {\n";
+        o << "  NextSet<U> n(nxt_mem);\n  (void)cur_mem;\n";
+        for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) emit_classify(n);
+        for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) emit_phase_a(n);
+        for (uint32_t n = 0; n < N; n++) if (!is_finish(n) && deg(n) != 0) emit_phase_b(n);
+        for (uint32_t n = 0; n < N; n++) if (!is_finish(n) && has_phase_c(n)) emit_phase_c(n);
+        emit_end();
+        o << "}\n\n";
+    }
+
+    // Huge automata: the slot sets are in LDS anyway, so the step is cut into out-of-line functions of a few nodes
+    // each (one inlined function of several hundred edges takes the compiler tens of minutes).  Phase order is kept:
+    // all of A, then B in node order, then C in node order.
+    void emit_step_chunked() {
+        const uint32_t N = g.h.n_nodes;
+        const char* sig = "(uint32_t* cur_mem, uint32_t* nxt_mem, Input& in, const U i, const U len, const uint32_t ch, const bool final_pass,\n"
+                          "    bool& accept, bool& any_next, tb_t& TB, const bool active)";
+        const char* pre = "  SlotSet<U> c(cur_mem); NextSet<U> n(nxt_mem); (void)c; (void)n; (void)in; (void)ch; (void)any_next;\n";
+        std::vector<std::string> calls;
+        auto begin_fn = [&](const std::string& name) {
+            o << "template <class U>\n__device__ __attribute__((noinline)) void " << name << sig << " {\n" << pre;
+            calls.push_back(name);
+        };
+        begin_fn("step_a");
+        for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) { emit_classify(n); emit_phase_a(n); }
+        o << "}\n\n";
+        int chunk = 0;
+        uint32_t budget = 0;
+        bool open = false;
         for (uint32_t n = 0; n < N; n++) {
             if (is_finish(n) || deg(n) == 0) continue;
-            o << "  if (__any(here" << n << ")) {   // node " << n << "\n";
-            Sym s = cur_sym(n, "c.");
-            edges(n, s, "here" + num(n), 0, true, "    ");
-            o << "  }\n";
+            if (!open) { begin_fn("step_b" + num(chunk++)); open = true; budget = 0; }
+            emit_classify(n);
+            emit_phase_b(n);
+            budget += deg(n);
+            if (budget >= 24) { o << "}\n\n"; open = false; }
         }
-        // ---- phase C: unset-cell edges of waiting states (and of pos == len states in the final pass)
+        if (open) { o << "}\n\n"; open = false; }
+        chunk = 0;
         for (uint32_t n = 0; n < N; n++) {
-            if (is_finish(n)) continue;
-            bool has_digit = false;
-            for (uint32_t k = 0; k < deg(n); k++) has_digit = has_digit || (digit(edge(n, k)) >= 0 && !is_finish(edge(n, k).target));
-            if (!has_digit) continue;
-            o << "  { const bool late" << n << " = live" << n << " && !here" << n << ";\n";
-            o << "    if (__any(late" << n << ")) {\n";
-            Sym s = cur_sym(n, "c.");
-            for (uint32_t k = 0; k < deg(n); k++) {
-                const auto& e = edge(n, k);
-                if (eps(e) || digit(e) < 0 || is_finish(e.target)) continue;        // epsilon acceptance of the slot state: phase A
-                unset_cell(e, s, "late" + num(n), 0, false, "      ");
-            }
-            o << "    }\n  }\n";
+            if (is_finish(n) || !has_phase_c(n)) continue;
+            if (!open) { begin_fn("step_c" + num(chunk++)); open = true; budget = 0; }
+            emit_classify(n);
+            emit_phase_c(n);
+            budget += deg(n);
+            if (budget >= 24) { o << "}\n\n"; open = false; }
         }
-        // ---- end of step
-        o << "  any_next = false;\n";
-        for (uint32_t n = 0; n < N; n++)
-            if (!is_finish(n)) o << "  any_next = any_next || ne(U(n.P" << n << "), konst<U>(MFA_EMPTY), TB);\n";
-        for (const auto& w : slot_words()) o << "  c." << w << " = n." << w << ";\n";
+        if (open) { o << "}\n\n"; open = false; }
+        begin_fn("step_end");
+        emit_end();
+        o << "}\n\n";
+        o << "template <class U>\n__device__ __forceinline__ void mfa_step(SlotSet<U>&, Input& in, const U i, const U len, const uint32_t ch,\n"
+             "                                         const bool final_pass, bool& accept, bool& any_next, tb_t& TB, uint32_t* cur_mem,\n"
+             "                                         uint32_t* nxt_mem, const bool active) {\n";
+        for (const auto& f : calls) o << "  " << f << "<U>(cur_mem, nxt_mem, in, i, len, ch, final_pass, accept, any_next, TB, active);\n";
         o << "}\n\n";
     }
 
@@ -314,34 +382,43 @@ struct Gen {
         std::vector<std::string> words = slot_words();
         o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n" << kPrelude;
         o << "\n#define REV " << (rev ? "true" : "false") << "\n#define N_WORDS " << words.size() << "\n\n";
-        o << "template <class U> struct SlotSet {\n";
-        for (const auto& w : words) o << "  U " << w << ";\n";
-        o << "};\n\n";
-        // The set a step builds.  Plain steps keep it in registers.  Dual steps of larger automata would need
-        // four slot sets in registers at once (values and directions, current and next) and spill; their next
-        // set lives in LDS instead, [word][v|d][lane]: one bank per lane, conflict free.
-        const bool lds_next = words.size() > 24;
+        const bool huge = jit_slot_registers(g) > 272;
+        const uint32_t lanes = huge ? huge_lanes((uint32_t)words.size()) : 64u;
+        const uint32_t stride = huge ? lanes + 1 : 64u;
+        const bool lds_next = huge || words.size() > 24;
+        o << "#define LANES " << lanes << "u\n#define PSTRIDE " << stride << "u\n#define HUGE " << (huge ? 1 : 0) << "\n";
         o << "#define NEXT_IN_LDS " << (lds_next ? 1 : 0) << "\n";
+        // LDS-resident words: [word][v|d][column], one bank per column
         o << "struct LdsDual {\n  uint32_t* p;\n"
-             "  __device__ __forceinline__ operator Dual() const { return Dual{p[0], (int32_t)p[64]}; }\n"
-             "  __device__ __forceinline__ LdsDual& operator=(Dual d) { p[0] = d.v; p[64] = (uint32_t)d.d; return *this; }\n"
+             "  __device__ __forceinline__ operator Dual() const { return Dual{p[0], (int32_t)p[PSTRIDE]}; }\n"
+             "  __device__ __forceinline__ LdsDual& operator=(Dual d) { p[0] = d.v; p[PSTRIDE] = (uint32_t)d.d; return *this; }\n"
              "  __device__ __forceinline__ LdsDual& operator=(const LdsDual& o) { return *this = (Dual)o; }\n};\n";
-        o << "template <class U> struct NextSet;\n";
-        o << "template <> struct NextSet<uint32_t> {\n";
-        for (const auto& w : words) o << "  uint32_t " << w << ";\n";
-        o << "  static constexpr bool in_lds = false;\n  __device__ __forceinline__ explicit NextSet(uint32_t*) {}\n};\n";
-        if (lds_next) {
-            o << "template <> struct NextSet<Dual> {\n";
-            for (const auto& w : words) o << "  LdsDual " << w << ";\n";
-            o << "  static constexpr bool in_lds = true;\n  __device__ __forceinline__ explicit NextSet(uint32_t* m) :";
-            for (size_t k = 0; k < words.size(); k++) o << (k ? ", " : " ") << words[k] << "{m + " << 2 * k << " * 64}";
-            o << " {}\n};\n\n";
-        } else {
-            o << "template <> struct NextSet<Dual> {\n";
-            for (const auto& w : words) o << "  Dual " << w << ";\n";
-            o << "  static constexpr bool in_lds = false;\n  __device__ __forceinline__ explicit NextSet(uint32_t*) {}\n};\n\n";
-        }
-        emit_step();
+        o << "struct LdsPlain {\n  uint32_t* p;\n"
+             "  __device__ __forceinline__ operator uint32_t() const { return p[0]; }\n"
+             "  __device__ __forceinline__ LdsPlain& operator=(uint32_t v) { p[0] = v; return *this; }\n"
+             "  __device__ __forceinline__ LdsPlain& operator=(const LdsPlain& o) { return *this = (uint32_t)o; }\n};\n";
+        auto reg_struct = [&](const char* name, const char* type) {
+            o << "template <> struct " << name << "<" << type << "> {\n";
+            for (const auto& w : words) o << "  " << type << " " << w << ";\n";
+            o << "  static constexpr bool in_lds = false;\n  __device__ __forceinline__ explicit " << name << "(uint32_t*) {}\n};\n";
+        };
+        auto lds_struct = [&](const char* name, const char* type, const char* proxy) {
+            o << "template <> struct " << name << "<" << type << "> {\n";
+            for (const auto& w : words) o << "  " << proxy << " " << w << ";\n";
+            o << "  static constexpr bool in_lds = true;\n  __device__ __forceinline__ explicit " << name << "(uint32_t* m) :";
+            for (size_t k = 0; k < words.size(); k++) o << (k ? ", " : " ") << words[k] << "{m + " << 2 * k << " * PSTRIDE}";
+            o << " {}\n};\n";
+        };
+        // The current set: registers, except for huge automata.  The set a step builds: registers for plain steps of
+        // non-huge automata; dual steps of larger automata would need four slot sets in registers at once and spill, so
+        // their next set lives in LDS.
+        o << "template <class U> struct SlotSet;\ntemplate <class U> struct NextSet;\n";
+        if (huge) { lds_struct("SlotSet", "uint32_t", "LdsPlain"); lds_struct("SlotSet", "Dual", "LdsDual"); }
+        else { reg_struct("SlotSet", "uint32_t"); reg_struct("SlotSet", "Dual"); }
+        if (huge) lds_struct("NextSet", "uint32_t", "LdsPlain"); else reg_struct("NextSet", "uint32_t");
+        if (lds_next) lds_struct("NextSet", "Dual", "LdsDual"); else reg_struct("NextSet", "Dual");
+        o << "\n";
+        if (huge) emit_step_chunked(); else emit_step();
         // ---- kernel
         // small automata: ask for two waves per SIMD (<= 128 VGPRs); the plain step needs far fewer, only the dual
         // step is register hungry and may then spill a little -- it is rare
@@ -350,24 +427,29 @@ struct Gen {
              "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats) {\n";
         o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";
         o << "  const uint32_t lane = threadIdx.x & 63u;\n";
-        o << "#if NEXT_IN_LDS\n  __shared__ uint32_t nxt_lds[2 * N_WORDS * 64];\n  uint32_t* const nxt_mem = nxt_lds + lane;\n#else\n  uint32_t* const nxt_mem = nullptr;\n#endif\n";
+        o << "  const uint32_t col = lane < LANES ? lane : LANES;     // column of this lane in the LDS images (idle lanes share one)\n";
+        o << "#if HUGE\n  __shared__ uint32_t huge_lds[7 * N_WORDS * PSTRIDE];\n  uint32_t* const cur_mem = huge_lds + col;\n"
+             "  uint32_t* const nxt_mem = cur_mem + 2 * N_WORDS * PSTRIDE;\n"
+             "#elif NEXT_IN_LDS\n  __shared__ uint32_t nxt_lds[2 * N_WORDS * PSTRIDE];\n  uint32_t* const cur_mem = nullptr;\n  uint32_t* const nxt_mem = nxt_lds + col;\n"
+             "#else\n  uint32_t* const cur_mem = nullptr;\n  uint32_t* const nxt_mem = nullptr;\n#endif\n";
         o << "  // probe storage of this wave, [array][word][lane]: SA = slots at probe start, later the direction d;\n"
              "  // SB = slots at the start of the dual period; SD = direction carried between dual steps\n";
         // small automata keep it in LDS (3 x N_WORDS x 256 B per wave), larger ones in an L2-resident scratch buffer
-        const bool probe_lds = words.size() <= 64;      // 3 x 64 x 256 B = 48 KiB per wave at most
-        if (probe_lds) o << "  __shared__ uint32_t probe_lds[3 * N_WORDS * 64];\n  uint32_t* const SA = probe_lds + lane;\n  (void)scratch;\n";
-        else o << "  uint32_t* const SA = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u) + lane;\n";
-        o << "  uint32_t* const SB = SA + N_WORDS * 64u;\n  uint32_t* const SD = SB + N_WORDS * 64u;\n";
+        const bool probe_lds = words.size() <= 68;      // 3 x 68 x 256 B = 51 KiB per wave at most
+        if (huge) o << "  uint32_t* const SA = nxt_mem + 2 * N_WORDS * PSTRIDE;\n  (void)scratch;\n";
+        else if (probe_lds) o << "  __shared__ uint32_t probe_lds[3 * N_WORDS * PSTRIDE];\n  uint32_t* const SA = probe_lds + col;\n  (void)scratch;\n";
+        else o << "  uint32_t* const SA = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u) + col;\n";
+        o << "  uint32_t* const SB = SA + N_WORDS * PSTRIDE;\n  uint32_t* const SD = SB + N_WORDS * PSTRIDE;\n";
         o << "  Input in; in.bytes = bytes; in.total16 = (offsets[n] + 15u) & ~(uint64_t)15; input_reset(in, 0, 0);\n";
         o << "  in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;\n";
         o << "  bool active = false, exhausted = false, accept = false;\n  uint32_t i = 0, len = 0; uint64_t sid = 0;\n";
         o << "  // run acceleration: phase 0 idle, 1 = pp plain steps after saving the slots, 2 = pp dual steps\n";
         o << "  uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1;\n  tb_t TBacc = tb_init();\n";
-        o << "  SlotSet<uint32_t> c;\n";
+        o << "  SlotSet<uint32_t> c(cur_mem);\n";
         for (const auto& w : words) o << "  c." << w << " = " << (w[0] == 'P' ? "MFA_EMPTY" : "0u") << ";\n";
         o << "  for (;;) {\n";
         o << "    {\n      // hand strings to idle lanes: one atomic per wave, tickets dealt by lane rank\n"
-             "      const bool want = !active && !exhausted;\n      const unsigned long long wb = __ballot(want);\n"
+             "      const bool want = !active && !exhausted && lane < LANES;\n      const unsigned long long wb = __ballot(want);\n"
              "      if (wb) {\n        unsigned long long first = 0;\n"
              "        if (lane == (uint32_t)__builtin_ctzll(wb)) first = atomicAdd(counter, (unsigned long long)__builtin_popcountll(wb));\n"
              "        first = ((unsigned long long)__shfl((uint32_t)(first >> 32), __builtin_ctzll(wb)) << 32) | __shfl((uint32_t)first, __builtin_ctzll(wb));\n"
@@ -405,28 +487,28 @@ struct Gen {
              "    if (q != 0u) {\n"
              "      pp = ep_pp;\n"
              "      if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * pp + 24u) {\n";
-        for (size_t k = 0; k < words.size(); k++) o << "        SA[" << k << " * 64] = c." << words[k] << ";\n";
+        for (size_t k = 0; k < words.size(); k++) o << "        SA[" << k << " * PSTRIDE] = c." << words[k] << ";\n";
         o << "        phase = 1u; pk = 0u; st_probe++;\n      } else if (in.per_hi - i < 4u * q * mult + 24u) {\n"
              "        probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // region too short to be worth a probe: look again behind it\n"
              "      } else {\n        probe_at = i + 1u;                                       // does not fit this epoch's period: next epoch\n      }\n    }\n";
         o << "    bool any_next = false;\n    tb_t TB = tb_init();\n";
         o << "    if (__any(phase == 2u)) {\n";
         o << "      // dual step: lanes in phase 2 carry the direction saved in SD, the others d = 0 (their TB is ignored)\n";
-        o << "      const bool p2 = phase == 2u;\n      SlotSet<Dual> dc;\n      st_dual++;\n";
+        o << "      const bool p2 = phase == 2u;\n      SlotSet<Dual> dc(cur_mem);\n      st_dual++;\n";
         for (size_t k = 0; k < words.size(); k++)
-            o << "      dc." << words[k] << " = Dual{c." << words[k] << ", p2 ? (int32_t)SD[" << k << " * 64] : 0};\n";
+            o << "      dc." << words[k] << " = Dual{(uint32_t)c." << words[k] << ", p2 ? (int32_t)SD[" << k << " * PSTRIDE] : 0};\n";
         o << "      const Dual di{i, (int32_t)pp}, dlen{len, 0};\n";
         o << "      in.dual_p = p2 ? pp : 0u;\n";
         o << "      (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the periodic region\n";
         o << "      (void)eq(di, dlen, TB);\n";
-        o << "      mfa_step<Dual>(dc, in, di, dlen, ch, final_pass, accept, any_next, TB, nxt_mem);\n";
+        o << "      mfa_step<Dual>(dc, in, di, dlen, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active);\n";
         o << "      in.dual_p = 0u;\n";
         o << "      uint32_t skip = 0;\n";
         o << "      if (p2) {\n        tb_min(TBacc, TB.a, TB.b);\n        pk++;\n";
         o << "        if (pk == pp) {\n          const int64_t periods = tb_steps(TBacc);\n          bool same = !accept && any_next && periods > 1;\n";
         for (size_t k = 0; k < words.size(); k++)
-            o << "          same = same && dc." << words[k] << ".d == (int32_t)SA[" << k << " * 64] && dc." << words[k] << ".v - SB[" << k
-              << " * 64] == SA[" << k << " * 64];\n";
+            o << "          { const Dual t = dc." << words[k] << "; same = same && t.d == (int32_t)SA[" << k << " * PSTRIDE] && t.v - SB[" << k
+              << " * PSTRIDE] == SA[" << k << " * PSTRIDE]; }\n";
         o << "          if (same) skip = (uint32_t)(periods - 1 < (int64_t)0x00ffffff ? periods - 1 : (int64_t)0x00ffffff);\n";
         o << "          phase = 0u;\n";
         o << "          if (skip) { backoff = 8u; fails = 0u; st_hit++; st_skip += (unsigned long long)skip * pp; }\n";
@@ -435,20 +517,21 @@ struct Gen {
              "          phase = 0u; fails++; mult = mult % 8u + 1u;             // cannot succeed any more: stop the probe here\n"
              "          if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
              "        } else {\n";
-        for (size_t k = 0; k < words.size(); k++) o << "          SD[" << k << " * 64] = (uint32_t)dc." << words[k] << ".d;\n";
+        for (size_t k = 0; k < words.size(); k++) o << "          SD[" << k << " * PSTRIDE] = (uint32_t)Dual(dc." << words[k] << ").d;\n";
         o << "        }\n      }\n";
-        for (size_t k = 0; k < words.size(); k++) o << "      c." << words[k] << " = dc." << words[k] << ".v + skip * (uint32_t)dc." << words[k] << ".d;\n";
+        for (size_t k = 0; k < words.size(); k++)
+            o << "      { const Dual t = dc." << words[k] << "; c." << words[k] << " = t.v + skip * (uint32_t)t.d; }\n";
         o << "      if (skip) { i += skip * pp; in.blk = ~(uint64_t)0; in.pblk = ~(uint64_t)0; probe_at = i + 1u + pp; }\n";
         o << "      else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);\n";
         o << "      if (phase == 1u) pk++;\n";
         o << "    } else {\n";
-        o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB, nxt_mem);\n";
+        o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active);\n";
         o << "      if (phase == 1u) pk++;\n";
         o << "    }\n";
         o << "    if (phase == 1u && pk == pp) {\n      // one period done: direction d = slots - saved slots; start the dual period from here\n";
         for (size_t k = 0; k < words.size(); k++) {
-            o << "      { const uint32_t d = c." << words[k] << " - SA[" << k << " * 64]; SA[" << k << " * 64] = d; SD[" << k << " * 64] = d; SB[" << k
-              << " * 64] = c." << words[k] << "; }\n";
+            o << "      { const uint32_t v = c." << words[k] << ", d = v - SA[" << k << " * PSTRIDE]; SA[" << k << " * PSTRIDE] = d; SD[" << k
+              << " * PSTRIDE] = d; SB[" << k << " * PSTRIDE] = v; }\n";
         }
         o << "      phase = 2u; pk = 0u; TBacc = tb_init();\n    }\n";
         o << "    if (active) {\n      const bool done = accept || final_pass || !any_next;\n      i++;\n"
@@ -470,6 +553,12 @@ struct Gen {
 uint32_t jit_slot_registers(const HostImage& img) {
     uint32_t K = img.h.n_cells ? img.h.n_cells : 1;
     return (img.h.n_nodes - 1) * (1 + 3 * K) * 2;
+}
+
+// string-carrying lanes per wave of the specialised kernel (64 unless the automaton is huge), 0 = cannot be specialised
+uint32_t jit_lanes(const HostImage& img) {
+    if (jit_slot_registers(img) <= 272) return 64;
+    return huge_lanes(jit_slot_registers(img) / 2);
 }
 
 std::string jit_generate_source(const HostImage& img) {

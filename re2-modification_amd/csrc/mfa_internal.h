@@ -60,6 +60,7 @@ struct DeviceState {
     void*               jit_fn  = nullptr;     // hipFunction_t
     int                 jit_waves_per_cu = 0;
     uint32_t            jit_words = 0;         // words per slot set of the specialised kernel
+    uint32_t            jit_lanes = 64;        // string-carrying lanes per wave
 };
 
 }  // namespace mfa
@@ -81,6 +82,7 @@ int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_byte
 int device_prepare(mfa_image* img, int device, DeviceState** out);
 // specialised kernels (jit_gen.cpp, jit.hip)
 uint32_t    jit_slot_registers(const HostImage& img);
+uint32_t    jit_lanes(const HostImage& img);
 std::string jit_generate_source(const HostImage& img);
 bool        jit_enabled(const HostImage& img);
 std::string jit_compile(const HostImage& img, std::string* err);

@@ -51,8 +51,7 @@ def test_golden(auto, jit, monkeypatch):
     elif jit == "generic":
         assert kern == capi.KERNEL_GENERIC
     else:
-        small = (image.blob_info(blob)["n_nodes"] - 1) * (1 + 3 * max(1, image.blob_info(blob)["n_cells"])) * 2 <= 272
-        assert kern == (capi.KERNEL_SPECIALISED if small else capi.KERNEL_GENERIC)
+        assert kern == capi.KERNEL_SPECIALISED          # every fixture automaton has a specialised kernel
     img.close()
 
 
