@@ -65,7 +65,7 @@ int device_prepare(mfa_image* img, int device, DeviceState** out) {
         if (rc == MFA_OK) rc = up((void**)&ds.d_byte_class, h.byte_class, 256);
     }
     if (rc == MFA_OK) {
-        hipError_t e = hipMalloc((void**)&ds.d_counter, 128 + (getenv("MFA_STATS") ? (4u << 20) : 0));
+        hipError_t e = hipMalloc((void**)&ds.d_counter, 256 + (getenv("MFA_STATS") ? (4u << 20) : 0));
         if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&ds.ev_start);
         if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&ds.ev_stop);
         if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }

@@ -406,6 +406,7 @@ __device__ __forceinline__ bool read_matches(Input& in, uint32_t i, uint32_t ch,
         }
         return in.run_hi - i >= l;
     }
+    if (((fl >> 8) & 0xffu) != ch) return false;          // first byte of the value (kept in the flags) against the byte at i
     return spans_equal<REV>(in, start, i, l);
 }
 
@@ -473,7 +474,14 @@ __device__ __forceinline__ bool read_pre_u(Input& in, U i, uint32_t ch, U start,
         }
         return ge(sub(run_hi_u(in, i, TB), i), l, TB);
     }
+    // bits 8..15 of the flags always hold the FIRST byte of a non-empty value (act_open_u / act_none_u): a read whose
+    // first byte already differs from the byte at i fails without touching memory
+    if (((fl >> 8) & 0xffu) != ch) return false;
     spans_period_bound(in, i, start, l, TB);
+    // the first 16 bytes per lane (all lanes at once); only reads that survive them go to the wave-wide comparison
+    const uint32_t lv = val(l), head = lv < 16u ? lv : 16u;
+    if (!spans_equal<REV>(in, REV ? val(start) + (lv - head) : val(start), REV ? val(i) + (lv - head) : val(i), head)) return false;
+    if (lv <= 16u) return true;
     need_cmp = true;
     return false;
 }

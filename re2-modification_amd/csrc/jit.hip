@@ -23,7 +23,7 @@ extern char** environ;
 
 namespace mfa {
 
-static const char* kGeneratorVersion = "jit-30";
+static const char* kGeneratorVersion = "jit-35";
 
 static std::string cache_dir() {
     if (const char* e = getenv("MFA_JIT_CACHE")) return e;
@@ -147,7 +147,7 @@ int launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_of
     }
     // MFA_STATS=1: the kernel adds its iteration / probe counters to 6 words behind the ticket counter
     unsigned long long* stats = getenv("MFA_STATS") ? ds.d_counter + 1 : nullptr;      // + per-string executed steps at stats+8 (u32, first 1M strings)
-    if (stats) (void)hipMemsetAsync(stats, 0, 6 * sizeof(unsigned long long), s);
+    if (stats) (void)hipMemsetAsync(stats, 0, 16 * sizeof(unsigned long long), s);
     void* args[] = {(void*)&d_bytes, (void*)&d_offsets, (void*)&n, (void*)&d_results, (void*)&ds.d_counter, (void*)&accel,
                     (void*)&ds.d_scratch, (void*)&stats};
     if (ds.timed) (void)hipEventRecord((hipEvent_t)ds.ev_start, s);
@@ -160,17 +160,19 @@ int launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_of
 // debugging aid: copy the counters of the last launch (MFA_STATS=1) to the host and print them
 void jit_print_stats(DeviceState& ds, const char* tag) {
     if (!getenv("MFA_STATS") || !ds.d_counter) return;
-    unsigned long long h[7] = {0};
+    unsigned long long h[17] = {0};
     if (hipMemcpy(h, ds.d_counter, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
     if (const char* path = getenv("MFA_STATS_FILE")) {
         std::vector<uint32_t> steps(1u << 20);
-        if (hipMemcpy(steps.data(), ds.d_counter + 9, steps.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (hipMemcpy(steps.data(), ds.d_counter + 17, steps.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
             FILE* f = fopen(path, "wb");
             if (f) { fwrite(steps.data(), 4, steps.size(), f); fclose(f); }
         }
     }
     fprintf(stderr, "mfa_hip stats %s: wave-iterations %llu (dual %llu), lane-steps skipped %llu, probes %llu (hits %llu), scans %llu\n", tag,
             h[1], h[2], h[3], h[4], h[5], h[6]);
+    if (h[10]) fprintf(stderr, "mfa_hip stats %s: share of wave time -- period scans %.1f%%, plain steps %.1f%%, dual steps %.1f%% (steps include cell-read scans)\n", tag,
+                      100.0 * h[7] / h[10], 100.0 * h[8] / h[10], 100.0 * h[9] / h[10]);
 }
 
 void jit_unload(DeviceState& ds) {

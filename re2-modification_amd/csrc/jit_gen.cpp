@@ -105,9 +105,9 @@ struct Gen {
         o << ind << "  n.P" << m << " = sel(" << w << ", " << pv << ", U(n.P" << m << "));\n";
         for (int c = 0; c < K; c++) {
             std::string sfx = num(m) + "_" + num(c);
-            o << ind << "  n.S" << sfx << " = sel(" << w << ", U(" << t.S[c] << "), U(n.S" << sfx << "));";
-            o << " n.L" << sfx << " = sel(" << w << ", U(" << t.L[c] << "), U(n.L" << sfx << "));";
-            o << " n.F" << sfx << " = sel(" << w << ", U(" << t.F[c] << "), U(n.F" << sfx << "));\n";
+            o << ind << "  assign_if(n.S" << sfx << ", " << w << ", U(" << t.S[c] << "));";
+            o << " assign_if(n.L" << sfx << ", " << w << ", U(" << t.L[c] << "));";
+            o << " assign_if(n.F" << sfx << ", " << w << ", U(" << t.F[c] << "));\n";
         }
         o << ind << "  }\n" << ind << "}\n";
     }
@@ -397,6 +397,11 @@ struct Gen {
              "  __device__ __forceinline__ operator uint32_t() const { return p[0]; }\n"
              "  __device__ __forceinline__ LdsPlain& operator=(uint32_t v) { p[0] = v; return *this; }\n"
              "  __device__ __forceinline__ LdsPlain& operator=(const LdsPlain& o) { return *this = (uint32_t)o; }\n};\n";
+        // conditional assignment of a slot word: a select for registers, a predicated store (no read) for LDS words
+        o << "__device__ __forceinline__ void assign_if(uint32_t& x, bool w, uint32_t v) { x = w ? v : x; }\n"
+             "__device__ __forceinline__ void assign_if(Dual& x, bool w, Dual v) { x = sel(w, v, x); }\n"
+             "__device__ __forceinline__ void assign_if(LdsDual x, bool w, Dual v) { if (w) { x.p[0] = v.v; x.p[PSTRIDE] = (uint32_t)v.d; } }\n"
+             "__device__ __forceinline__ void assign_if(LdsPlain x, bool w, uint32_t v) { if (w) x.p[0] = v; }\n";
         auto reg_struct = [&](const char* name, const char* type) {
             o << "template <> struct " << name << "<" << type << "> {\n";
             for (const auto& w : words) o << "  " << type << " " << w << ";\n";
@@ -416,7 +421,20 @@ struct Gen {
         if (huge) { lds_struct("SlotSet", "uint32_t", "LdsPlain"); lds_struct("SlotSet", "Dual", "LdsDual"); }
         else { reg_struct("SlotSet", "uint32_t"); reg_struct("SlotSet", "Dual"); }
         if (huge) lds_struct("NextSet", "uint32_t", "LdsPlain"); else reg_struct("NextSet", "uint32_t");
-        if (lds_next) lds_struct("NextSet", "Dual", "LdsDual"); else reg_struct("NextSet", "Dual");
+        if (huge) lds_struct("NextSet", "Dual", "LdsDual");
+        else if (lds_next) {
+            // keys (P words) stay in registers so that the comparison of an insert needs no LDS round trip; S/L/F words in LDS
+            o << "template <> struct NextSet<Dual> {\n";
+            for (const auto& w : words) o << "  " << (w[0] == 'P' ? "Dual" : "LdsDual") << " " << w << ";\n";
+            o << "  static constexpr bool in_lds = true;\n  __device__ __forceinline__ explicit NextSet(uint32_t* m) :";
+            bool first = true;
+            for (size_t k = 0; k < words.size(); k++) {
+                if (words[k][0] == 'P') continue;
+                o << (first ? " " : ", ") << words[k] << "{m + " << 2 * k << " * PSTRIDE}";
+                first = false;
+            }
+            o << " {}\n};\n";
+        } else reg_struct("NextSet", "Dual");
         o << "\n";
         if (huge) emit_step_chunked(); else emit_step();
         // ---- kernel
@@ -426,6 +444,7 @@ struct Gen {
              "const uint64_t* __restrict__ offsets, uint64_t n,\n               uint8_t* __restrict__ results, "
              "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats) {\n";
         o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";
+        o << "  unsigned long long tm_scan = 0, tm_plain = 0, tm_dual = 0, tm_total = stats ? clock64() : 0;\n";
         o << "  const uint32_t lane = threadIdx.x & 63u;\n";
         o << "  const uint32_t col = lane < LANES ? lane : LANES;     // column of this lane in the LDS images (idle lanes share one)\n";
         o << "#if HUGE\n  __shared__ uint32_t huge_lds[7 * N_WORDS * PSTRIDE];\n  uint32_t* const cur_mem = huge_lds + col;\n"
@@ -474,12 +493,14 @@ struct Gen {
              "      if (rest < 8u) q = 0u;\n"
              "    }\n"
              "    bool need_scan = q != 0u && !(in.per_q == q && in.per_lo <= i && i < in.per_hi);\n"
+             "    const unsigned long long tm0 = stats ? clock64() : 0;\n"
              "    for (unsigned long long sb = __ballot(need_scan); sb; sb &= sb - 1ull) {          // one string at a time, all lanes scanning\n"
              "      const int L = __builtin_ctzll(sb);\n"
              "      const uint64_t sbase = ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L);\n"
              "      const uint32_t r = coop_period_end<REV>(bytes, sbase, __shfl(len, L), __shfl(i, L), __shfl(q, L), lane);\n"
              "      if (lane == (uint32_t)L) { in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++; }\n"
              "    }\n"
+             "    if (stats) tm_scan += clock64() - tm0;\n"
              "    if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
              "    if (q != 0u && q * mult > 16u) mult = 1u;\n"
              "    const unsigned long long cand = __ballot(q != 0u && in.per_hi - i >= 4u * q * mult + 24u);\n"
@@ -491,7 +512,7 @@ struct Gen {
         o << "        phase = 1u; pk = 0u; st_probe++;\n      } else if (in.per_hi - i < 4u * q * mult + 24u) {\n"
              "        probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // region too short to be worth a probe: look again behind it\n"
              "      } else {\n        probe_at = i + 1u;                                       // does not fit this epoch's period: next epoch\n      }\n    }\n";
-        o << "    bool any_next = false;\n    tb_t TB = tb_init();\n";
+        o << "    bool any_next = false;\n    tb_t TB = tb_init();\n    const unsigned long long tm1 = stats ? clock64() : 0;\n";
         o << "    if (__any(phase == 2u)) {\n";
         o << "      // dual step: lanes in phase 2 carry the direction saved in SD, the others d = 0 (their TB is ignored)\n";
         o << "      const bool p2 = phase == 2u;\n      SlotSet<Dual> dc(cur_mem);\n      st_dual++;\n";
@@ -523,10 +544,10 @@ struct Gen {
             o << "      { const Dual t = dc." << words[k] << "; c." << words[k] << " = t.v + skip * (uint32_t)t.d; }\n";
         o << "      if (skip) { i += skip * pp; in.blk = ~(uint64_t)0; in.pblk = ~(uint64_t)0; probe_at = i + 1u + pp; }\n";
         o << "      else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);\n";
-        o << "      if (phase == 1u) pk++;\n";
+        o << "      if (phase == 1u) pk++;\n      if (stats) tm_dual += clock64() - tm1;\n";
         o << "    } else {\n";
         o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active);\n";
-        o << "      if (phase == 1u) pk++;\n";
+        o << "      if (phase == 1u) pk++;\n      if (stats) tm_plain += clock64() - tm1;\n";
         o << "    }\n";
         o << "    if (phase == 1u && pk == pp) {\n      // one period done: direction d = slots - saved slots; start the dual period from here\n";
         for (size_t k = 0; k < words.size(); k++) {
@@ -536,11 +557,12 @@ struct Gen {
         o << "      phase = 2u; pk = 0u; TBacc = tb_init();\n    }\n";
         o << "    if (active) {\n      const bool done = accept || final_pass || !any_next;\n      i++;\n"
              "      st_steps++;\n      if (done) { results[sid] = accept ? 1 : 0; active = false; phase = 0u;\n"
-             "        if (stats && sid < (1u << 20)) ((uint32_t*)(stats + 8))[sid] = st_steps;\n        st_steps = 0;\n";
+             "        if (stats && sid < (1u << 20)) ((uint32_t*)(stats + 16))[sid] = st_steps;\n        st_steps = 0;\n";
         for (const auto& w : words)
             if (w[0] == 'P') o << "        c." << w << " = MFA_EMPTY;\n";
         o << "      }\n    }\n  }\n";
-        o << "  if (stats) {\n    if (lane == 0) { atomicAdd(&stats[0], st_iter); atomicAdd(&stats[1], st_dual); }\n"
+        o << "  if (stats) {\n    if (lane == 0) { atomicAdd(&stats[0], st_iter); atomicAdd(&stats[1], st_dual); atomicAdd(&stats[6], tm_scan); atomicAdd(&stats[7], tm_plain);\n"
+             "      atomicAdd(&stats[8], tm_dual); atomicAdd(&stats[9], (unsigned long long)clock64() - tm_total); }\n"
              "    atomicAdd(&stats[2], st_skip); atomicAdd(&stats[3], st_probe); atomicAdd(&stats[4], st_hit); atomicAdd(&stats[5], st_scan);\n  }\n}\n";
         (void)N;
         return o.str();

@@ -19,7 +19,7 @@ def gpu_match(img, strings):
     import torch
     data, off = oracle_lib.pack(strings)
     d_bytes = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
-    d_bytes[:len(data)] = torch.from_numpy(data)
+    d_bytes[:len(data)] = torch.from_numpy(data.copy())
     d_off = torch.from_numpy(off.astype(np.int64)).cuda()
     res = img.match_tensors(d_bytes, d_off)
     torch.cuda.synchronize()
@@ -177,3 +177,61 @@ def test_full_length_attack_strings(ex):
     want = oracle_lib.OracleImage(blob).match(strings)
     got = gpu_match(capi.Image(blob), strings)
     assert list(got) == list(want)
+
+
+def test_edge_cases():
+    """Empty batch, empty strings, ragged lengths, a string at and above the length limit."""
+    import torch
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex1_plain"))
+    img = capi.Image(blob)
+    # n = 0: nothing to do, no launch
+    off0 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    assert img.match_tensors(torch.zeros(64, dtype=torch.uint8, device="cuda"), off0).numel() == 0
+    # empty strings between non-empty ones (the empty string matches ({a*}:1&1)*), ragged lengths 0..70
+    strings = [b"", b"a", b"", b"aa", b"b", b""] + [b"a" * k for k in range(71)] + [b"a" * k + b"b" for k in range(40)]
+    want = oracle_lib.OracleImage(blob).match(strings)
+    assert list(gpu_match(img, strings)) == list(want)
+    assert want[0] == 1 and want[4] == 0
+    # a memory-less automaton on the same ragged batch
+    nfa_blob = image.blob_from_dump(oracle_lib.load_dump("nfa_abb_thompson"))
+    s2 = [b"", b"abb", b"a" * 17 + b"abb", b"b" * 129 + b"abb", b"abb" + b"a" * 200] + [b"ab" * k + b"abb" for k in range(60)]
+    assert list(gpu_match(capi.Image(nfa_blob), s2)) == list(oracle_lib.OracleImage(nfa_blob).match(s2))
+    # exactly at the limit is matched, one byte more is flagged 2 by the device entry point and refused by the host one
+    limit = 0x00ffffff
+    big = torch.full((limit + 1 + 64,), ord("a"), dtype=torch.uint8, device="cuda")
+    off = torch.tensor([0, limit], dtype=torch.int64, device="cuda")
+    r = img.match_tensors(big, off)
+    torch.cuda.synchronize()
+    assert int(r[0]) == 1                                   # a^n matches
+    off = torch.tensor([0, limit + 1], dtype=torch.int64, device="cuda")
+    r = img.match_tensors(big, off)
+    torch.cuda.synchronize()
+    assert int(r[0]) == 2
+    data = np.full(limit + 1, ord("a"), dtype=np.uint8)
+    with pytest.raises(capi.MfaError) as e:
+        img.match_host(data, np.array([0, limit + 1], dtype=np.uint64))
+    assert e.value.code == capi.ERR_TOO_LONG
+
+
+def test_streams_and_reuse():
+    """One image used from two streams with different batches, and re-used after that: results stay per batch."""
+    import torch
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex6_plain"))
+    img1, img2 = capi.Image(blob), capi.Image(blob)
+    sa = oracle_lib.load_set("pump6")
+    sb = oracle_lib.load_set("rnd")
+    da, oa = oracle_lib.pack(sa)
+    db, ob = oracle_lib.pack(sb)
+    ta = torch.zeros(len(da) + 64, dtype=torch.uint8, device="cuda"); ta[:len(da)] = torch.from_numpy(da.copy())
+    tb = torch.zeros(len(db) + 64, dtype=torch.uint8, device="cuda"); tb[:len(db)] = torch.from_numpy(db.copy())
+    oa_t, ob_t = torch.from_numpy(oa.astype(np.int64)).cuda(), torch.from_numpy(ob.astype(np.int64)).cuda()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    ra = img1.match_tensors(ta, oa_t, stream=s1)
+    rb = img2.match_tensors(tb, ob_t, stream=s2)
+    torch.cuda.synchronize()
+    assert np.array_equal(ra.cpu().numpy(), oracle_lib.load_bits("ex6_plain", "pump6"))
+    assert np.array_equal(rb.cpu().numpy(), oracle_lib.load_bits("ex6_plain", "rnd"))
+    rb2 = img1.match_tensors(tb, ob_t)
+    torch.cuda.synchronize()
+    assert np.array_equal(rb2.cpu().numpy(), oracle_lib.load_bits("ex6_plain", "rnd"))
