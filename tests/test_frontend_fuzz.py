@@ -1,0 +1,106 @@
+"""Random regexes through the host front-end against the reference itself (needs oracle/_ref/ref_harness, i.e. the
+build container; skipped elsewhere): the automaton images must be identical, node order and edge order included."""
+import os
+import random
+import subprocess
+
+import pytest
+
+import oracle_lib
+
+DIPLOMA = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
+HARNESS = os.path.join(oracle_lib.ROOT, "oracle", "_ref", "ref_harness")
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(HARNESS) and os.path.exists(DIPLOMA)),
+                                reason="needs the reference harness (build container only)")
+
+
+def rand_regex(rng, depth, cells, allow_mem):
+    """A random regex of the README grammar (README.md:11-24): literals, '.', concatenation, alternation in
+    parentheses, star on a parenthesised group or a literal, and -- if allow_mem -- {r}:k and &k."""
+    if depth <= 0:
+        r = rng.random()
+        if allow_mem and cells and r < 0.25:
+            return "&" + rng.choice(cells)
+        return rng.choice("abc.") if r < 0.95 else rng.choice("ab")
+    kind = rng.random()
+    if kind < 0.35:
+        return "".join(rand_regex(rng, depth - 1, cells, allow_mem) for _ in range(rng.randint(2, 3)))
+    if kind < 0.55:
+        return "(" + "|".join(rand_regex(rng, depth - 1, cells, allow_mem) for _ in range(rng.randint(2, 3))) + ")"
+    if kind < 0.75:
+        return "(" + rand_regex(rng, depth - 1, cells, allow_mem) + ")*"
+    if kind < 0.85 and allow_mem:
+        k = rng.choice("12")
+        if k not in cells:
+            cells.append(k)
+        return "{" + rand_regex(rng, depth - 1, cells, False) + "}:" + k
+    return rng.choice("abc") + "*"
+
+
+def dump_pair(regex, flag, mode, tmp):
+    a = subprocess.run([DIPLOMA, "-dump"] + flag, input=regex + "\n", capture_output=True, text=True, cwd=tmp)
+    b = subprocess.run([HARNESS, "dump", mode, regex], capture_output=True, text=True, cwd=tmp)
+    return a, b
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_regexes_match_reference(seed, tmp_path):
+    rng = random.Random(1000 + seed)
+    checked = 0
+    for _ in range(40):
+        mem = rng.random() < 0.6
+        regex = rand_regex(rng, rng.randint(1, 3), [], mem)
+        if len(regex) < 2:
+            continue
+        if mem and ("{" in regex or "&" in regex):
+            modes = [(["-mfa"], "mfa"), ([], "plain")]
+        else:
+            modes = [(["-thompson"], "thompson"), (["-glushkov"], "glushkov"), ([], "plain")]
+        for flag, mode in modes:
+            a, b = dump_pair(regex, flag, mode, tmp_path)
+            if b.returncode != 0 or "UNKNOWN" in b.stdout:
+                continue                      # the reference itself cannot build this one
+            assert a.returncode == 0, (regex, mode, a.stderr)
+            assert a.stdout == b.stdout, "regex %r mode %s" % (regex, mode)
+            checked += 1
+    assert checked > 40
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_restatement_on_random_regexes(seed, tmp_path):
+    """The CPU restatement against the reference on automata and strings outside the committed fixtures."""
+    import numpy as np
+    from mfa_amd import image
+    rng = random.Random(5000 + seed)
+    done = 0
+    for _ in range(30):
+        if done >= 8:
+            break
+        regex = rand_regex(rng, rng.randint(2, 3), [], True)
+        if "{" not in regex and "&" not in regex:
+            continue
+        d = subprocess.run([HARNESS, "dump", "mfa", regex], capture_output=True, text=True, cwd=tmp_path)
+        if d.returncode != 0 or "UNKNOWN" in d.stdout:
+            continue
+        try:
+            blob = image.blob_from_dump(d.stdout)
+        except image.ImageError:
+            continue
+        strings = []
+        for _k in range(150):
+            n = rng.randint(0, 40)
+            strings.append("".join(rng.choice("aaabbc") for _ in range(n)))
+        for _k in range(30):
+            w = "".join(rng.choice("ab") for _ in range(rng.randint(1, 3)))
+            strings.append(w * rng.randint(1, 30) + rng.choice(["", "a", "b", "c"]))
+        strings = [s for s in strings if s]                       # the harness reads lines; keep it simple
+        r = subprocess.run([HARNESS, "match", "mfa", regex], input="".join(s + "\n" for s in strings), capture_output=True, text=True,
+                           cwd=tmp_path)
+        assert r.returncode == 0
+        want = np.array([int(c) for c in r.stdout.split()], dtype=np.uint8)
+        got = oracle_lib.OracleImage(blob).match([s.encode() for s in strings])
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "regex %r: %d mismatches, first %r want %d" % (regex, bad.size, strings[bad[0]], want[bad[0]])
+        done += 1
+    assert done >= 4

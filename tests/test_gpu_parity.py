@@ -235,3 +235,48 @@ def test_streams_and_reuse():
     rb2 = img1.match_tensors(tb, ob_t)
     torch.cuda.synchronize()
     assert np.array_equal(rb2.cpu().numpy(), oracle_lib.load_bits("ex6_plain", "rnd"))
+
+
+def _front_end_blob(regex, tmp_path, flag="-mfa"):
+    import subprocess
+    diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
+    p = subprocess.run([diploma, "-dump", flag], input=regex + "\n", capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 0, p.stderr
+    return image.blob_from_dump(p.stdout)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_random_regexes_on_gpu(seed, tmp_path, monkeypatch):
+    """Automata nobody has seen before: random regexes of the README grammar through the host front-end, matched by
+    the table-driven kernel (all of them) and by a freshly generated specialised kernel (the first one per seed),
+    against the CPU restatement."""
+    import random
+    from test_frontend_fuzz import rand_regex
+    rng = random.Random(9000 + seed)
+    done = 0
+    for _ in range(40):
+        if done >= 6:
+            break
+        regex = rand_regex(rng, rng.randint(2, 3), [], True)
+        if "{" not in regex and "&" not in regex:
+            continue
+        try:
+            blob = _front_end_blob(regex, tmp_path)
+        except (AssertionError, image.ImageError):
+            continue
+        strings = [("".join(rng.choice("aaabbc") for _ in range(rng.randint(0, 60)))).encode() for _k in range(200)]
+        strings += [(("".join(rng.choice("ab") for _ in range(rng.randint(1, 3)))) * rng.randint(1, 400) + rng.choice(["", "a", "c"])).encode()
+                    for _k in range(60)]
+        want = oracle_lib.OracleImage(blob).match(strings)
+        for mode in (["generic", "specialised"] if done == 0 else ["generic"]):
+            monkeypatch.setenv("MFA_JIT", "0" if mode == "generic" else "1")
+            try:
+                img = capi.Image(blob)
+            except capi.MfaError as e:
+                assert e.code == capi.ERR_UNSUPPORTED      # outside the kernels' structural limits: refused, not mis-matched
+                break
+            got = gpu_match(img, strings)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, "regex %r (%s): %d mismatches, first %r want %d" % (regex, mode, bad.size, strings[bad[0]], want[bad[0]])
+        done += 1
+    assert done >= 3
