@@ -280,3 +280,35 @@ def test_random_regexes_on_gpu(seed, tmp_path, monkeypatch):
             assert bad.size == 0, "regex %r (%s): %d mismatches, first %r want %d" % (regex, mode, bad.size, strings[bad[0]], want[bad[0]])
         done += 1
     assert done >= 3
+
+
+@pytest.mark.parametrize("ex", range(1, 11))
+def test_acceleration_changes_nothing_on_the_bench_corpus(ex, monkeypatch):
+    """The benchmark's own strings (pump sizes up to 64 KiB): the accelerated walk, the same kernel executing every
+    step (MFA_ACCEL=0) and -- on a prefix of the batch -- the table-driven kernel must give identical answers.  Size
+    independent property: three different ways through the same semantics."""
+    import torch
+    from mfa_amd import corpus
+    n = 12000
+    sizes = corpus.pump_sizes(n, 0x5EED0004 + ex, 1024, 65536)
+    ws = (np.arange(n) % 2) == 0
+    d_bytes, d_off = corpus.device_batch(ex, sizes, ws, torch.device("cuda", 0))
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex))
+    img = capi.Image(blob)
+    monkeypatch.setenv("MFA_ACCEL", "1")
+    fast = img.match_tensors(d_bytes, d_off).clone()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("MFA_ACCEL", "0")
+    slow = img.match_tensors(d_bytes, d_off).clone()
+    torch.cuda.synchronize()
+    assert torch.equal(fast, slow)
+    monkeypatch.setenv("MFA_JIT", "0")
+    m = 600
+    generic = capi.Image(blob).match_tensors(d_bytes, d_off[:m + 1].clone())
+    torch.cuda.synchronize()
+    assert torch.equal(generic, fast[:m])
+    # and the short ones among them against the CPU restatement
+    short = [k for k in range(n) if sizes[k] <= 3000][:40]
+    strings = corpus.host_strings(ex, sizes[short], ws[short])
+    want = oracle_lib.OracleImage(blob).match(strings)
+    assert list(fast[short].cpu().numpy()) == list(want)
