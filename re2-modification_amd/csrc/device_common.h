@@ -338,14 +338,18 @@ __device__ __forceinline__ uint32_t val(Dual a) { return a.v; }
 // outcome?  Every comparison contributes a bound of the form ceil(a / b), a, b > 0, and the minimum of
 // ceilings is the ceiling of the minimum, so TB is kept as the smallest fraction seen (compared by cross
 // multiplication) and divided once per step.
-struct tb_t { int64_t a, b; };
-__device__ __forceinline__ tb_t tb_init() { return tb_t{(int64_t)1 << 30, 1}; }
+struct tb_t { int64_t a; uint32_t b; };                              // a / b, 0 < a < 2^34, 0 < b <= 2^20
+__device__ __forceinline__ tb_t tb_init() { return tb_t{(int64_t)1 << 30, 1u}; }
 __device__ __forceinline__ void tb_min(tb_t& TB, int64_t a, int64_t b) {
-    if (b > ((int64_t)1 << 20)) { a = 1; b = 1; }                      // absurd slope: give up on this step (keeps products in range)
-    if (a * TB.b < TB.a * b) { TB.a = a; TB.b = b; }
+    if (b > ((int64_t)1 << 20) || a > ((int64_t)1 << 34)) {           // absurd slope or distance: give up on this step / no constraint
+        if (b > ((int64_t)1 << 20)) { a = 1; b = 1; } else return;
+    }
+    // a / b < TB.a / TB.b  <=>  a * TB.b < TB.a * b   (64 x 32 bit products, < 2^54)
+    if ((uint64_t)a * TB.b < (uint64_t)TB.a * (uint32_t)b) { TB.a = a; TB.b = (uint32_t)b; }
 }
 __device__ __forceinline__ void tb_min(tb_t& TB, int64_t t) { tb_min(TB, t, 1); }
 __device__ __forceinline__ int64_t tb_steps(const tb_t& TB) { return (TB.a + TB.b - 1) / TB.b; }
+__device__ __forceinline__ bool tb_is_one(const tb_t& TB) { return TB.a <= (int64_t)TB.b; }   // tb_steps(TB) <= 1, without dividing
 
 // a < b now; bounds TB by the number of steps for which the outcome stays the same
 __device__ __forceinline__ bool lt(uint32_t a, uint32_t b, tb_t&) { return a < b; }

@@ -534,7 +534,7 @@ struct Gen {
         o << "          phase = 0u;\n";
         o << "          if (skip) { backoff = 8u; fails = 0u; st_hit++; st_skip += (unsigned long long)skip * pp; }\n";
         o << "          else { fails++; mult = mult % 8u + 1u; if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; } }\n";
-        o << "        } else if (tb_steps(TBacc) <= 1 || accept || !any_next) {\n"
+        o << "        } else if (tb_is_one(TBacc) || accept || !any_next) {\n"
              "          phase = 0u; fails++; mult = mult % 8u + 1u;             // cannot succeed any more: stop the probe here\n"
              "          if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
              "        } else {\n";
