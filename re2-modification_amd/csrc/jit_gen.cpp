@@ -381,7 +381,7 @@ struct Gen {
         const uint32_t N = g.h.n_nodes;
         std::vector<std::string> words = slot_words();
         o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n" << kPrelude;
-        o << "\n#define REV " << (rev ? "true" : "false") << "\n#define N_WORDS " << words.size() << "\n\n";
+        o << "\n#define REV " << (rev ? "true" : "false") << "\n#define N_WORDS " << words.size() << "\n#define N_KEYS " << (N - 1) << "\n\n";
         const bool huge = jit_slot_registers(g) > 272;
         const uint32_t lanes = huge ? huge_lanes((uint32_t)words.size()) : 64u;
         const uint32_t stride = huge ? lanes + 1 : 64u;
@@ -428,9 +428,10 @@ struct Gen {
             for (const auto& w : words) o << "  " << (w[0] == 'P' ? "Dual" : "LdsDual") << " " << w << ";\n";
             o << "  static constexpr bool in_lds = true;\n  __device__ __forceinline__ explicit NextSet(uint32_t* m) :";
             bool first = true;
+            size_t kk = 0;                       // LDS words are numbered without the keys
             for (size_t k = 0; k < words.size(); k++) {
                 if (words[k][0] == 'P') continue;
-                o << (first ? " " : ", ") << words[k] << "{m + " << 2 * k << " * PSTRIDE}";
+                o << (first ? " " : ", ") << words[k] << "{m + " << 2 * kk++ << " * PSTRIDE}";
                 first = false;
             }
             o << " {}\n};\n";
@@ -449,21 +450,39 @@ struct Gen {
         o << "  const uint32_t col = lane < LANES ? lane : LANES;     // column of this lane in the LDS images (idle lanes share one)\n";
         o << "#if HUGE\n  __shared__ uint32_t huge_lds[7 * N_WORDS * PSTRIDE];\n  uint32_t* const cur_mem = huge_lds + col;\n"
              "  uint32_t* const nxt_mem = cur_mem + 2 * N_WORDS * PSTRIDE;\n"
-             "#elif NEXT_IN_LDS\n  __shared__ uint32_t nxt_lds[2 * N_WORDS * PSTRIDE];\n  uint32_t* const cur_mem = nullptr;\n  uint32_t* const nxt_mem = nxt_lds + col;\n"
+             "#elif NEXT_IN_LDS\n  __shared__ uint32_t nxt_lds[2 * (N_WORDS - N_KEYS) * PSTRIDE];\n  uint32_t* const cur_mem = nullptr;\n  uint32_t* const nxt_mem = nxt_lds + col;\n"
              "#else\n  uint32_t* const cur_mem = nullptr;\n  uint32_t* const nxt_mem = nullptr;\n#endif\n";
-        o << "  // probe storage of this wave, [array][word][lane]: SA = slots at probe start, later the direction d;\n"
-             "  // SB = slots at the start of the dual period; SD = direction carried between dual steps\n";
-        // small automata keep it in LDS (3 x N_WORDS x 256 B per wave), larger ones in an L2-resident scratch buffer
-        const bool probe_lds = words.size() <= 68;      // 3 x 68 x 256 B = 51 KiB per wave at most
-        if (huge) o << "  uint32_t* const SA = nxt_mem + 2 * N_WORDS * PSTRIDE;\n  (void)scratch;\n";
-        else if (probe_lds) o << "  __shared__ uint32_t probe_lds[3 * N_WORDS * PSTRIDE];\n  uint32_t* const SA = probe_lds + col;\n  (void)scratch;\n";
-        else o << "  uint32_t* const SA = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u) + col;\n";
-        o << "  uint32_t* const SB = SA + N_WORDS * PSTRIDE;\n  uint32_t* const SD = SB + N_WORDS * PSTRIDE;\n";
+        o << "  // probe storage of this wave, [array][word][column]: SB = slots at probe start, from the dual period on the slots at its\n"
+             "  // start; SA = the direction d measured over the first period; SD = direction carried between dual steps\n";
+        // small automata keep it in LDS, larger ones in an L2-resident scratch buffer
+        const bool probe_lds = words.size() <= 68;
+        if (huge) {
+            o << "  uint32_t* const SAm = nxt_mem + 2 * N_WORDS * PSTRIDE;\n  uint32_t* const SBm = SAm + N_WORDS * PSTRIDE;\n"
+                 "  uint32_t* const SDm = SBm + N_WORDS * PSTRIDE;\n  (void)scratch;\n"
+                 "#define SA_RD(k) ((int32_t)SAm[(k) * PSTRIDE])\n#define SA_WR(k, v) (SAm[(k) * PSTRIDE] = (uint32_t)(v))\n"
+                 "#define SD_RD(k) ((int32_t)SDm[(k) * PSTRIDE])\n#define SD_WR(k, v) (SDm[(k) * PSTRIDE] = (uint32_t)(v))\n"
+                 "#define SB_RD(k) (SBm[(k) * PSTRIDE])\n#define SB_WR(k, v) (SBm[(k) * PSTRIDE] = (v))\n";
+        } else if (probe_lds) {
+            // directions are small numbers: 16 bits each (a probe whose direction does not fit is abandoned).  SD is only
+            // live between two dual steps and the LDS next set only inside one: they share memory.
+            o << "  __shared__ uint32_t probe_sb[N_WORDS * 64];\n  __shared__ int16_t probe_sa[N_WORDS * 64];\n";
+            o << "#if NEXT_IN_LDS\n  int16_t* const probe_sd = reinterpret_cast<int16_t*>(nxt_lds);\n#else\n  __shared__ int16_t probe_sd[N_WORDS * 64];\n#endif\n";
+            o << "  (void)scratch;\n"
+                 "#define SA_RD(k) ((int32_t)probe_sa[(k) * 64 + col])\n#define SA_WR(k, v) (probe_sa[(k) * 64 + col] = (int16_t)(v))\n"
+                 "#define SD_RD(k) ((int32_t)probe_sd[(k) * 64 + col])\n#define SD_WR(k, v) (probe_sd[(k) * 64 + col] = (int16_t)(v))\n"
+                 "#define SB_RD(k) (probe_sb[(k) * 64 + col])\n#define SB_WR(k, v) (probe_sb[(k) * 64 + col] = (v))\n";
+        } else {
+            o << "  uint32_t* const SAm = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u) + col;\n  uint32_t* const SBm = SAm + N_WORDS * 64u;\n"
+                 "  uint32_t* const SDm = SBm + N_WORDS * 64u;\n"
+                 "#define SA_RD(k) ((int32_t)SAm[(k) * 64])\n#define SA_WR(k, v) (SAm[(k) * 64] = (uint32_t)(v))\n"
+                 "#define SD_RD(k) ((int32_t)SDm[(k) * 64])\n#define SD_WR(k, v) (SDm[(k) * 64] = (uint32_t)(v))\n"
+                 "#define SB_RD(k) (SBm[(k) * 64])\n#define SB_WR(k, v) (SBm[(k) * 64] = (v))\n";
+        }
         o << "  Input in; in.bytes = bytes; in.total16 = (offsets[n] + 15u) & ~(uint64_t)15; input_reset(in, 0, 0);\n";
         o << "  in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;\n";
         o << "  bool active = false, exhausted = false, accept = false;\n  uint32_t i = 0, len = 0; uint64_t sid = 0;\n";
         o << "  // run acceleration: phase 0 idle, 1 = pp plain steps after saving the slots, 2 = pp dual steps\n";
-        o << "  uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1;\n  tb_t TBacc = tb_init();\n";
+        o << "  uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1;\n  tb_t TBacc = tb_init();\n  bool fits = true;        // every direction of the running probe fits its 16-bit store\n";
         o << "  SlotSet<uint32_t> c(cur_mem);\n";
         for (const auto& w : words) o << "  c." << w << " = " << (w[0] == 'P' ? "MFA_EMPTY" : "0u") << ";\n";
         o << "  for (;;) {\n";
@@ -508,7 +527,7 @@ struct Gen {
              "    if (q != 0u) {\n"
              "      pp = ep_pp;\n"
              "      if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * pp + 24u) {\n";
-        for (size_t k = 0; k < words.size(); k++) o << "        SA[" << k << " * PSTRIDE] = c." << words[k] << ";\n";
+        for (size_t k = 0; k < words.size(); k++) o << "        SB_WR(" << k << ", (uint32_t)c." << words[k] << ");\n";
         o << "        phase = 1u; pk = 0u; st_probe++;\n      } else if (in.per_hi - i < 4u * q * mult + 24u) {\n"
              "        probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // region too short to be worth a probe: look again behind it\n"
              "      } else {\n        probe_at = i + 1u;                                       // does not fit this epoch's period: next epoch\n      }\n    }\n";
@@ -517,7 +536,7 @@ struct Gen {
         o << "      // dual step: lanes in phase 2 carry the direction saved in SD, the others d = 0 (their TB is ignored)\n";
         o << "      const bool p2 = phase == 2u;\n      SlotSet<Dual> dc(cur_mem);\n      st_dual++;\n";
         for (size_t k = 0; k < words.size(); k++)
-            o << "      dc." << words[k] << " = Dual{(uint32_t)c." << words[k] << ", p2 ? (int32_t)SD[" << k << " * PSTRIDE] : 0};\n";
+            o << "      dc." << words[k] << " = Dual{(uint32_t)c." << words[k] << ", p2 ? SD_RD(" << k << ") : 0};\n";
         o << "      const Dual di{i, (int32_t)pp}, dlen{len, 0};\n";
         o << "      in.dual_p = p2 ? pp : 0u;\n";
         o << "      (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the periodic region\n";
@@ -526,10 +545,10 @@ struct Gen {
         o << "      in.dual_p = 0u;\n";
         o << "      uint32_t skip = 0;\n";
         o << "      if (p2) {\n        tb_min(TBacc, TB.a, TB.b);\n        pk++;\n";
-        o << "        if (pk == pp) {\n          const int64_t periods = tb_steps(TBacc);\n          bool same = !accept && any_next && periods > 1;\n";
+        o << "        if (pk == pp) {\n          const int64_t periods = tb_steps(TBacc);\n          bool same = !accept && any_next && periods > 1 && fits;\n";
         for (size_t k = 0; k < words.size(); k++)
-            o << "          { const Dual t = dc." << words[k] << "; same = same && t.d == (int32_t)SA[" << k << " * PSTRIDE] && t.v - SB[" << k
-              << " * PSTRIDE] == SA[" << k << " * PSTRIDE]; }\n";
+            o << "          { const Dual t = dc." << words[k] << "; same = same && t.d == SA_RD(" << k << ") && (int32_t)(t.v - SB_RD(" << k
+              << ")) == SA_RD(" << k << "); }\n";
         o << "          if (same) skip = (uint32_t)(periods - 1 < (int64_t)0x00ffffff ? periods - 1 : (int64_t)0x00ffffff);\n";
         o << "          phase = 0u;\n";
         o << "          if (skip) { backoff = 8u; fails = 0u; st_hit++; st_skip += (unsigned long long)skip * pp; }\n";
@@ -538,7 +557,8 @@ struct Gen {
              "          phase = 0u; fails++; mult = mult % 8u + 1u;             // cannot succeed any more: stop the probe here\n"
              "          if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
              "        } else {\n";
-        for (size_t k = 0; k < words.size(); k++) o << "          SD[" << k << " * PSTRIDE] = (uint32_t)Dual(dc." << words[k] << ").d;\n";
+        for (size_t k = 0; k < words.size(); k++)
+            o << "          { const int32_t d = Dual(dc." << words[k] << ").d; SD_WR(" << k << ", d); fits = fits && d == (int32_t)(int16_t)d; }\n";
         o << "        }\n      }\n";
         for (size_t k = 0; k < words.size(); k++)
             o << "      { const Dual t = dc." << words[k] << "; c." << words[k] << " = t.v + skip * (uint32_t)t.d; }\n";
@@ -549,10 +569,10 @@ struct Gen {
         o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active);\n";
         o << "      if (phase == 1u) pk++;\n      if (stats) tm_plain += clock64() - tm1;\n";
         o << "    }\n";
-        o << "    if (phase == 1u && pk == pp) {\n      // one period done: direction d = slots - saved slots; start the dual period from here\n";
+        o << "    if (phase == 1u && pk == pp) {\n      // one period done: direction d = slots - saved slots; start the dual period from here\n      fits = true;\n";
         for (size_t k = 0; k < words.size(); k++) {
-            o << "      { const uint32_t v = c." << words[k] << ", d = v - SA[" << k << " * PSTRIDE]; SA[" << k << " * PSTRIDE] = d; SD[" << k
-              << " * PSTRIDE] = d; SB[" << k << " * PSTRIDE] = v; }\n";
+            o << "      { const uint32_t v = c." << words[k] << "; const int32_t d = (int32_t)(v - SB_RD(" << k << ")); SA_WR(" << k << ", d); SD_WR(" << k
+              << ", d); SB_WR(" << k << ", v); fits = fits && d == (int32_t)(int16_t)d; }\n";
         }
         o << "      phase = 2u; pk = 0u; TBacc = tb_init();\n    }\n";
         o << "    if (active) {\n      const bool done = accept || final_pass || !any_next;\n      i++;\n"
