@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--max-len", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="HIP streams the ten launches of a step are spread over (longest-processing-time-first); "
+                         "the runtime maps streams onto four hardware queues, more streams gain nothing")
     ap.add_argument("--sequential", dest="concurrent", action="store_false",
                     help="launch the ten examples one after another on one stream instead of on ten streams")
     args = ap.parse_args()
@@ -235,23 +238,43 @@ def main():
     # one HIP stream per example: the ten launches of a step are independent, so they run concurrently and
     # the chip is not left idle while one example's longest strings finish
     main = torch.cuda.current_stream(device)
-    streams = {ex: (torch.cuda.Stream(device) if args.concurrent else main) for ex in shards}
     ev_fork = torch.cuda.Event(enable_timing=True)
     ev_join = torch.cuda.Event(enable_timing=True)
     ev_done = {ex: torch.cuda.Event() for ex in shards}
+    res_pos, pos = {}, 0
+    for ex, sh in shards.items():
+        res_pos[ex] = pos
+        pos += sh["n"]
+    # batching policy (setup, untimed): one back-to-back pass measures each example's kernel time; the launches of a
+    # step are then spread over --streams HIP streams longest-first, each onto the least loaded stream, so that the
+    # long examples start at once and no stream is left with a long kernel at the end of the step
+    order = list(shards)
+    streams = {ex: main for ex in shards}
+    if args.concurrent and args.streams > 1:
+        for ex, sh in shards.items():
+            sh["img"].match_tensors(sh["bytes"], sh["off"], results[res_pos[ex]:res_pos[ex] + sh["n"]], stream=main)
+        torch.cuda.synchronize()
+        cost = {ex: shards[ex]["img"].last_kernel_ms(local) for ex in shards}
+        pool = [torch.cuda.Stream(device) for _ in range(min(args.streams, len(shards)))]
+        load = [0.0] * len(pool)
+        queue = [[] for _ in pool]
+        for ex in sorted(shards, key=lambda e: -cost[e]):
+            k = load.index(min(load))
+            load[k] += cost[ex]
+            queue[k].append(ex)
+            streams[ex] = pool[k]
+        order = [q[j] for j in range(max(len(q) for q in queue)) for q in queue if j < len(q)]
 
     def step(record):
-        pos = 0
         ev_fork.record(main)
-        for ex, sh in shards.items():
-            st = streams[ex]
+        for ex in order:
+            sh, st = shards[ex], streams[ex]
             if st is not main:
                 st.wait_event(ev_fork)
-            sh["img"].match_tensors(sh["bytes"], sh["off"], results[pos:pos + sh["n"]], stream=st)
+            sh["img"].match_tensors(sh["bytes"], sh["off"], results[res_pos[ex]:res_pos[ex] + sh["n"]], stream=st)
             if st is not main:
                 ev_done[ex].record(st)
                 main.wait_event(ev_done[ex])
-            pos += sh["n"]
         ev_join.record(main)
         bitmap = sharding.pack_bitmap(results)
         if dist:
@@ -326,7 +349,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "%s: 10 launches per step, one per example, %s" % (
                              "/".join(sorted({kinds[sh["img"].info()["last_kernel"]] for sh in shards.values()})),
-                             "concurrent on 10 streams (duration = fork-to-join span)" if args.concurrent else "back to back on one stream"),
+                             "concurrent on %d streams, longest first (duration = fork-to-join span)" % args.streams if args.concurrent else "back to back on one stream"),
                          "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s},
             "per_example": per_ex,
         }

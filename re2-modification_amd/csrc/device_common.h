@@ -8,6 +8,10 @@
 #ifndef MFA_DEVICE_COMMON_H
 #define MFA_DEVICE_COMMON_H
 
+// loads in flight per lane in the wave-cooperative scans; the specialised kernels trade depth for registers (occupancy)
+#ifndef MFA_SCAN_DEPTH
+#define MFA_SCAN_DEPTH 8
+#endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -202,7 +206,7 @@ __device__ __forceinline__ uint32_t coop_period_end_fwd(const uint8_t* bytes, ui
     const uint8_t* p = bytes + base;
     const uint32_t last = len - q;                       // compare j with j+q for i0 <= j < last
     const uint32_t nblk = (last - i0) >> 4;              // whole 16-byte blocks
-    constexpr int D = 8;                                 // 16-byte blocks per lane in flight: 8 KiB per wave and trip
+    constexpr int D = MFA_SCAN_DEPTH;                    // 16-byte blocks per lane in flight: D KiB per wave and trip
     const uint32_t cc = (uint32_t)p[i0] * 0x01010101u;   // q == 1: every byte must equal the first one
     for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
         uint4 x[D], y[D];
@@ -251,7 +255,7 @@ __device__ __forceinline__ uint32_t coop_period_end_rev(const uint8_t* bytes, ui
     const uint8_t* top = bytes + base + (len - 1u - i0);  // address of scan index i0
     const uint32_t last = len - q;                        // compare j with j+q for i0 <= j < last
     const uint32_t nblk = (last - i0) >> 4;
-    constexpr int D = 8;
+    constexpr int D = MFA_SCAN_DEPTH;
     for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
         uint4 x[D], y[D];
 #pragma unroll
@@ -299,7 +303,7 @@ __device__ __forceinline__ bool coop_mem_equal(const uint8_t* bytes, uint64_t pa
     const uint8_t* a = bytes + pa;
     const uint8_t* b = bytes + pb;
     const uint32_t nblk = l >> 4;
-    constexpr int D = 8;
+    constexpr int D = MFA_SCAN_DEPTH;
     for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
         uint4 x[D], y[D];
 #pragma unroll

@@ -23,7 +23,7 @@ extern char** environ;
 
 namespace mfa {
 
-static const char* kGeneratorVersion = "jit-38";
+static const char* kGeneratorVersion = "jit-45";
 
 static std::string cache_dir() {
     if (const char* e = getenv("MFA_JIT_CACHE")) return e;
@@ -42,9 +42,17 @@ static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
     return h;
 }
 
+static bool stats_build() {
+    const char* e = getenv("MFA_STATS");
+    return e && e[0] != '0' && e[0] != 0;
+}
+
 static std::string image_key(const HostImage& img) {
     uint64_t h = 1469598103934665603ull;
     h = fnv1a(kGeneratorVersion, strlen(kGeneratorVersion), h);
+    if (stats_build()) h = fnv1a("stats", 5, h);
+    for (const char* k : {"MFA_GEN_SCAN_DEPTH", "MFA_GEN_LB2_WORDS", "MFA_GEN_LDS_BUDGET", "MFA_GEN_PROBE_PERIODS"})
+        if (const char* e = getenv(k)) h = fnv1a(e, strlen(e), fnv1a(k, strlen(k), h));
     h = fnv1a(&img.h, sizeof img.h, h);
     h = fnv1a(img.edge_begin.data(), img.edge_begin.size() * 4, h);
     h = fnv1a(img.edges.data(), img.edges.size() * sizeof(mfa_blob_edge), h);
@@ -82,7 +90,9 @@ std::string jit_compile(const HostImage& img, std::string* err) {
     char tmpl[64];
     snprintf(tmpl, sizeof tmpl, ".tmp%d_%u", (int)getpid(), serial.fetch_add(1));
     std::string tmp = obj + tmpl, log = tmp + ".log";
-    std::string cmd = cc + " --genco --offload-arch=gfx950 -O3 -std=c++17 -o '" + tmp + "' '" + src + "' > '" + log + "' 2>&1";
+    // the resource-usage remarks (VGPRs, LDS, scratch, occupancy) of a successful build are kept next to the object
+    std::string cmd = cc + " --genco --offload-arch=gfx950 -O3 -std=c++17 -Rpass-analysis=kernel-resource-usage" +
+                      (stats_build() ? " -DMFA_STATS_BUILD=1" : "") + " -o '" + tmp + "' '" + src + "' > '" + log + "' 2>&1";
     const char* argv[] = {"/bin/sh", "-c", cmd.c_str(), nullptr};
     pid_t pid;
     if (posix_spawn(&pid, "/bin/sh", nullptr, nullptr, (char* const*)argv, environ) != 0) {
@@ -97,7 +107,7 @@ std::string jit_compile(const HostImage& img, std::string* err) {
         return "";
     }
     rename(tmp.c_str(), obj.c_str());
-    unlink(log.c_str());
+    rename(log.c_str(), (dir + "/" + key + ".log").c_str());
     return obj;
 }
 
@@ -132,6 +142,7 @@ int launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_of
     hipError_t e = hipMemsetAsync(ds.d_counter, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
     uint64_t grid = (uint64_t)ds.n_cus * ds.jit_waves_per_cu, want = (n + ds.jit_lanes - 1) / ds.jit_lanes;
+    if (const char* spl = getenv("MFA_STRINGS_PER_LANE")) { const uint64_t k = (uint64_t)atoi(spl); if (k > 1) want = (want + k - 1) / k; }
     if (grid > want) grid = want;
     if (grid == 0) grid = 1;
     const char* ae = getenv("MFA_ACCEL");
@@ -171,6 +182,7 @@ void jit_print_stats(DeviceState& ds, const char* tag) {
     }
     fprintf(stderr, "mfa_hip stats %s: wave-iterations %llu (dual %llu), lane-steps skipped %llu, probes %llu (hits %llu), scans %llu\n", tag,
             h[1], h[2], h[3], h[4], h[5], h[6]);
+    fprintf(stderr, "mfa_hip stats %s: failed probes -- never settled %llu, dual period %llu, out of periodic input %llu\n", tag, h[11], h[12], h[13]);
     if (h[10]) fprintf(stderr, "mfa_hip stats %s: share of wave time -- period scans %.1f%%, plain steps %.1f%%, dual steps %.1f%% (steps include cell-read scans)\n", tag,
                       100.0 * h[7] / h[10], 100.0 * h[8] / h[10], 100.0 * h[9] / h[10]);
 }

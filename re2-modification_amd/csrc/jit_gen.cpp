@@ -55,6 +55,12 @@ static uint32_t huge_lanes(uint32_t n_words) {
     return 0;
 }
 
+// development knobs (folded into the cache key by jit.hip)
+static int knob(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : dflt;
+}
+
 struct Gen {
     const HostImage& g;
     std::ostringstream o;
@@ -380,7 +386,7 @@ struct Gen {
     std::string run() {
         const uint32_t N = g.h.n_nodes;
         std::vector<std::string> words = slot_words();
-        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n" << kPrelude;
+        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 8) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
         o << "\n#define REV " << (rev ? "true" : "false") << "\n#define N_WORDS " << words.size() << "\n#define N_KEYS " << (N - 1) << "\n\n";
         const bool huge = jit_slot_registers(g) > 272;
         const uint32_t lanes = huge ? huge_lanes((uint32_t)words.size()) : 64u;
@@ -441,9 +447,11 @@ struct Gen {
         // ---- kernel
         // small automata: ask for two waves per SIMD (<= 128 VGPRs); the plain step needs far fewer, only the dual
         // step is register hungry and may then spill a little -- it is rare
-        o << "extern \"C\" __global__ void __launch_bounds__(64" << (words.size() <= 20 ? ", 2" : "") << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
+        o << "extern \"C\" __global__ void __launch_bounds__(64" << (!huge && (int)words.size() <= knob("MFA_GEN_LB2_WORDS", 20) ? ", 2" : "") << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
              "const uint64_t* __restrict__ offsets, uint64_t n,\n               uint8_t* __restrict__ results, "
-             "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats) {\n";
+             "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats_arg) {\n";
+        // the counters cost a dozen VGPRs: they exist only in objects compiled with -DMFA_STATS_BUILD=1 (MFA_STATS=1)
+        o << "  unsigned long long* const stats = MFA_STATS_BUILD ? stats_arg : nullptr;\n";
         o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";
         o << "  unsigned long long tm_scan = 0, tm_plain = 0, tm_dual = 0, tm_total = stats ? clock64() : 0;\n";
         o << "  const uint32_t lane = threadIdx.x & 63u;\n";
@@ -465,7 +473,18 @@ struct Gen {
         } else if (probe_lds) {
             // directions are small numbers: 16 bits each (a probe whose direction does not fit is abandoned).  SD is only
             // live between two dual steps and the LDS next set only inside one: they share memory.
-            o << "  __shared__ uint32_t probe_sb[N_WORDS * 64];\n  __shared__ int16_t probe_sa[N_WORDS * 64];\n";
+            // LDS budget for two waves per SIMD: 20 KiB a wave.  The next set comes first, then SA, then SB; what does not
+            // fit lives in the wave's (L2-resident) scratch area and is touched a few times per probe only.
+            const size_t nkeys = (size_t)std::count_if(words.begin(), words.end(), [](const std::string& w) { return w[0] == 'P'; });
+            size_t lds = lds_next ? 2 * (words.size() - nkeys) * 256 : words.size() * 128;
+            const size_t budget = (size_t)knob("MFA_GEN_LDS_BUDGET", 65536);
+            const bool sa_lds = lds + words.size() * 128 <= budget;
+            if (sa_lds) lds += words.size() * 128;
+            const bool sb_lds = sa_lds && lds + words.size() * 256 <= budget;
+            if (sb_lds) o << "  __shared__ uint32_t probe_sb[N_WORDS * 64];\n";
+            else o << "  uint32_t* const probe_sb = scratch + (size_t)blockIdx.x * (3u * N_WORDS * 64u);\n";
+            if (sa_lds) o << "  __shared__ int16_t probe_sa[N_WORDS * 64];\n";
+            else o << "  int16_t* const probe_sa = reinterpret_cast<int16_t*>(probe_sb + N_WORDS * 64);\n";
             o << "#if NEXT_IN_LDS\n  int16_t* const probe_sd = reinterpret_cast<int16_t*>(nxt_lds);\n#else\n  __shared__ int16_t probe_sd[N_WORDS * 64];\n#endif\n";
             o << "  (void)scratch;\n"
                  "#define SA_RD(k) ((int32_t)probe_sa[(k) * 64 + col])\n#define SA_WR(k, v) (probe_sa[(k) * 64 + col] = (int16_t)(v))\n"
@@ -482,7 +501,11 @@ struct Gen {
         o << "  in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;\n";
         o << "  bool active = false, exhausted = false, accept = false;\n  uint32_t i = 0, len = 0; uint64_t sid = 0;\n";
         o << "  // run acceleration: phase 0 idle, 1 = pp plain steps after saving the slots, 2 = pp dual steps\n";
-        o << "  uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1;\n  tb_t TBacc = tb_init();\n  bool fits = true;        // every direction of the running probe fits its 16-bit store\n";
+        o << "  uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1, nper = 0;\n  tb_t TBacc = tb_init();\n"
+             "  bool fits = true;        // every direction of the running probe fits its 16-bit store\n"
+             "  bool stable = false;     // the last two plain periods moved the slots by the same amounts\n"
+             "  bool patient = false;    // a dual period right after the first plain one has failed on this string: wait for two equal movements\n"
+             "  unsigned long long st_f_unst = 0, st_f_dual = 0, st_f_room = 0;\n";
         o << "  SlotSet<uint32_t> c(cur_mem);\n";
         for (const auto& w : words) o << "  c." << w << " = " << (w[0] == 'P' ? "MFA_EMPTY" : "0u") << ";\n";
         o << "  for (;;) {\n";
@@ -495,7 +518,7 @@ struct Gen {
              "          if (sid >= n) exhausted = true;\n          else {\n            const uint64_t b = offsets[sid], e = offsets[sid + 1];\n"
              "            if (e - b > MFA_DEV_MAX_LEN) results[sid] = 2;\n            else {\n"
              "              len = (uint32_t)(e - b); input_reset(in, b, len);\n"
-             "              i = 0; accept = false; active = true; phase = 0; probe_at = 0; backoff = 8; pp = 1; fails = 0; mult = 1;\n";
+             "              i = 0; accept = false; active = true; phase = 0; probe_at = 0; backoff = 8; pp = 1; fails = 0; mult = 1; nper = 0; stable = false; patient = false;\n";
         for (const auto& w : words)
             o << "              c." << w << " = " << (w == "P" + num(g.h.start) ? "0u" : (w[0] == 'P' ? "MFA_EMPTY" : "0u")) << ";\n";
         o << "            }\n          }\n        }\n      }\n    }\n    if (!__any(active)) break;\n    st_iter++;\n";
@@ -528,7 +551,7 @@ struct Gen {
              "      pp = ep_pp;\n"
              "      if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * pp + 24u) {\n";
         for (size_t k = 0; k < words.size(); k++) o << "        SB_WR(" << k << ", (uint32_t)c." << words[k] << ");\n";
-        o << "        phase = 1u; pk = 0u; st_probe++;\n      } else if (in.per_hi - i < 4u * q * mult + 24u) {\n"
+        o << "        phase = 1u; pk = 0u; nper = 0u; stable = false; st_probe++;\n      } else if (in.per_hi - i < 4u * q * mult + 24u) {\n"
              "        probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // region too short to be worth a probe: look again behind it\n"
              "      } else {\n        probe_at = i + 1u;                                       // does not fit this epoch's period: next epoch\n      }\n    }\n";
         o << "    bool any_next = false;\n    tb_t TB = tb_init();\n    const unsigned long long tm1 = stats ? clock64() : 0;\n";
@@ -552,9 +575,13 @@ struct Gen {
         o << "          if (same) skip = (uint32_t)(periods - 1 < (int64_t)0x00ffffff ? periods - 1 : (int64_t)0x00ffffff);\n";
         o << "          phase = 0u;\n";
         o << "          if (skip) { backoff = 8u; fails = 0u; st_hit++; st_skip += (unsigned long long)skip * pp; }\n";
-        o << "          else { fails++; mult = mult % 8u + 1u; if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; } }\n";
+        // a failed dual period: after an optimistic start (one plain period) the next probe of this string waits for two
+        // equal movements; otherwise the slots may repeat with a multiple of the period
+        o << "          else { st_f_dual++; fails++; if (nper == 1u && !patient && pp > 2u) patient = true; else mult = mult % 8u + 1u;\n"
+             "            if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; } }\n";
         o << "        } else if (tb_is_one(TBacc) || accept || !any_next) {\n"
-             "          phase = 0u; fails++; mult = mult % 8u + 1u;             // cannot succeed any more: stop the probe here\n"
+             "          phase = 0u; fails++; st_f_dual++;                       // cannot succeed any more: stop the probe here\n"
+             "          if (nper == 1u && !patient && pp > 2u) patient = true; else mult = mult % 8u + 1u;\n"
              "          if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
              "        } else {\n";
         for (size_t k = 0; k < words.size(); k++)
@@ -569,12 +596,35 @@ struct Gen {
         o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active);\n";
         o << "      if (phase == 1u) pk++;\n      if (stats) tm_plain += clock64() - tm1;\n";
         o << "    }\n";
-        o << "    if (phase == 1u && pk == pp) {\n      // one period done: direction d = slots - saved slots; start the dual period from here\n      fits = true;\n";
+        // plain periods of a probe: after each one the movement of the slots over the period is compared with the previous
+        // period's; a lane is ready for the dual period once two consecutive movements agree.  All lanes of an epoch reach
+        // their period boundaries in the same iteration and go on together: to the dual period when every one of them is
+        // ready or has run out of patience (MFA_PROBE_PERIODS plain periods) or of periodic input.
+        o << "    if (phase == 1u && pk == pp) {\n      bool eqd = nper != 0u, occ = nper == 0u && !patient && pp > 2u;      // short periods: waiting for a second one costs next to nothing\n      fits = true;\n";
         for (size_t k = 0; k < words.size(); k++) {
-            o << "      { const uint32_t v = c." << words[k] << "; const int32_t d = (int32_t)(v - SB_RD(" << k << ")); SA_WR(" << k << ", d); SD_WR(" << k
-              << ", d); SB_WR(" << k << ", v); fits = fits && d == (int32_t)(int16_t)d; }\n";
+            o << "      { const uint32_t v = c." << words[k] << ", b = SB_RD(" << k << "); const int32_t d = (int32_t)(v - b); eqd = eqd && d == SA_RD(" << k
+              << "); SA_WR(" << k << ", d); SB_WR(" << k << ", v); fits = fits && d == (int32_t)(int16_t)d;";
+            if (words[k][0] == 'P') o << " occ = occ && (v == MFA_EMPTY) == (b == MFA_EMPTY);";
+            o << " }\n";
         }
-        o << "      phase = 2u; pk = 0u; TBacc = tb_init();\n    }\n";
+        // first period: the same slots occupied before and after it is taken as "probably settled already"
+        o << "      nper++; pk = 0u; stable = (eqd || occ) && fits;\n    }\n";
+        o << "    {\n      const bool at_b = phase == 1u && pk == 0u && nper != 0u;\n"
+             "      if (__any(at_b)) {\n"
+             "        const bool room = in.per_hi >= i + 1u + 2u * pp;          // the dual period and at least one more to skip\n"
+             "        if (!__any(at_b && !stable && room && nper < (pp > 2u ? MFA_PROBE_PERIODS : 3u))) {\n"
+             "          if (at_b && stable && room) {\n";
+        for (size_t k = 0; k < words.size(); k++) o << "            SD_WR(" << k << ", SA_RD(" << k << "));\n";
+        o << "            phase = 2u; TBacc = tb_init();\n"
+             "          } else if (at_b) {\n"
+             "            phase = 0u;\n"
+             "            if (!room) st_f_room++; else st_f_unst++;\n"
+             "            if (!room) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;\n"
+             "            else {                                                 // never settled: maybe the slots repeat with a multiple of the period\n"
+             "              fails++; mult = mult % 8u + 1u;\n"
+             "              if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
+             "              probe_at = i + 1u + (fails ? 0u : backoff);\n"
+             "            }\n          }\n        }\n      }\n    }\n";
         o << "    if (active) {\n      const bool done = accept || final_pass || !any_next;\n      i++;\n"
              "      st_steps++;\n      if (done) { results[sid] = accept ? 1 : 0; active = false; phase = 0u;\n"
              "        if (stats && sid < (1u << 20)) ((uint32_t*)(stats + 16))[sid] = st_steps;\n        st_steps = 0;\n";
@@ -583,7 +633,8 @@ struct Gen {
         o << "      }\n    }\n  }\n";
         o << "  if (stats) {\n    if (lane == 0) { atomicAdd(&stats[0], st_iter); atomicAdd(&stats[1], st_dual); atomicAdd(&stats[6], tm_scan); atomicAdd(&stats[7], tm_plain);\n"
              "      atomicAdd(&stats[8], tm_dual); atomicAdd(&stats[9], (unsigned long long)clock64() - tm_total); }\n"
-             "    atomicAdd(&stats[2], st_skip); atomicAdd(&stats[3], st_probe); atomicAdd(&stats[4], st_hit); atomicAdd(&stats[5], st_scan);\n  }\n}\n";
+             "    atomicAdd(&stats[2], st_skip); atomicAdd(&stats[3], st_probe); atomicAdd(&stats[4], st_hit); atomicAdd(&stats[5], st_scan);\n"
+             "    atomicAdd(&stats[10], st_f_unst); atomicAdd(&stats[11], st_f_dual); atomicAdd(&stats[12], st_f_room);\n  }\n}\n";
         (void)N;
         return o.str();
     }
