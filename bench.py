@@ -328,7 +328,7 @@ def main():
         # read from inside the run); only quoted when this run is the workload they were collected on
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01f_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01g_traffic.json")) as f:
                 tj = json.load(f)
             wl = tj["workload"]
             if (wl["strings_per_example"], wl["min_len"], wl["max_len"]) == (n_per, args.min_len, args.max_len) and args.concurrent:
@@ -343,7 +343,7 @@ def main():
             "config": {"workload": "10 README MFA examples (plain mode), %d pumped attack strings per example per GPU, "
                                    "pump size log-uniform [%d, %d], alternating with/without suffix "
                                    "(BASELINE configs[3] shard: 10M strings over 8 GPUs)" % (n_per, args.min_len, args.max_len),
-                       "strings_per_gpu": total_strings, "bytes_per_gpu": total_bytes, "parallelism": "dp%d" % world,
+                       "strings_per_example": n_per, "min_len": args.min_len, "max_len": args.max_len, "strings_per_gpu": total_strings, "bytes_per_gpu": total_bytes, "parallelism": "dp%d" % world,
                        "exchange": "gather of the result bitmap to rank 0" + (" (RCCL)" if dist else " (single rank: none)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
