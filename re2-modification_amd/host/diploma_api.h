@@ -251,4 +251,11 @@ void match(string regexp_str, bool reverse, bool bnf, bool ssnf, bool use_log = 
 void match_gt(string regexp_str, const string& input_path = "input_strings.txt");
 void match_mfa(string regexp_str, const string& input_path = "mfa_str.txt");
 
+// matchers/example_runner.cpp:15 -- the attack-string generator: only pump parts 0 and 1 are used
+std::string pumped_string(int n, vector<string> pump_v);
+// matchers/example_runner.cpp:84 (`./diploma -match N`): reads test/example_N/regexp.txt and pump.txt below
+// the working directory, matches ever longer pumped strings one at a time and writes "len seconds" lines to
+// test/example_N/diploma_results.txt until one match takes 0.5 s or longer (see drivers.cpp for what differs)
+void run_configuration_examples(const string& number);
+
 #endif  // DIPLOMA_API_H

@@ -3,7 +3,11 @@
 //                                              whitespace-separated token of stdin, until the token `exit`
 //   match_gt()   matchers/match_mfa.cpp:13-56  strings from a file against the Glushkov automaton
 //   match_mfa()  matchers/match_mfa.cpp:58-97  strings from a file against toMFA()'s automaton
+//   run_configuration_examples()  matchers/example_runner.cpp:84-151  `./diploma -match N`: growth curve of one example
 #include <chrono>
+#include <climits>
+#include <cstdint>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 
@@ -97,4 +101,70 @@ void match_mfa(string regexp_str, const string& input_path) {
     MFA* mfa = bt->toMFA();
     mfa->draw("mfa");
     match_file(nullptr, mfa, input_path, "results7.txt", true);
+}
+
+// ---- `./diploma -match N` ------------------------------------------------------------------------------
+// The reference's experiment (matchers/example_runner.cpp): the regex of test/example_N/regexp.txt (line 1) against
+// prefix + pumped_string(pump_size) + suffix for growing pump sizes, one "len seconds" line per string in
+// test/example_N/diploma_results.txt, until a match takes >= 0.5 s.  Kept from the reference: the files and their
+// format, the pump-size schedule (500, doubling every round and once more every tenth round), the prefix that
+// accumulates the previous string (example_runner.cpp:123 appends in place), the 0.5 s stop rule.  Different: the
+// time is wall time of one GPU match of one string (copy in, launch, copy out) instead of clock() around the CPU
+// loop; a running match is not interrupted, the series ends after the first slow one; strings beyond the device
+// limit (16 MiB) end the series; the `-bnf` / `-reverse` curves (diploma_bnf_results.txt, diploma_reverse_results.txt)
+// need regex/bnf.cpp and are not written -- the round counter that drives the extra doubling advances as if the
+// reversed automaton were still running, which is what happens in the reference until it times out.
+// DIPLOMA_FRESH_PREFIX=1 uses the file's prefix for every string (matcher.py:58), which is what bench.py measures.
+std::string pumped_string(int n, vector<string> pump_v) {
+    const int parts = (int)pump_v.size() / 2 + 1, joints = (int)pump_v.size() - parts;
+    string unit = pump_v[0];
+    while ((int)(unit.size() + pump_v[0].size()) < (n - joints) / parts) unit += pump_v[0];
+    string out;
+    out.reserve((unit.size() + (joints ? pump_v[1].size() : 0)) * (size_t)(joints + 1));
+    for (int k = 0; k < joints; k++) out += unit + pump_v[1];
+    return out + unit;
+}
+
+void run_configuration_examples(const string& number) {
+    const string dir = "test/example_" + number + "/";
+    std::ifstream regex_file(dir + "regexp.txt"), pump_file(dir + "pump.txt");
+    if (!regex_file.is_open() || !pump_file.is_open()) return;          // like the reference: nothing to do
+    string regexp_str, pump_line, suffix, prefix;
+    std::getline(regex_file, regexp_str);
+    std::getline(pump_file, pump_line);
+    std::getline(pump_file, suffix);
+    std::getline(pump_file, prefix);
+    vector<string> pump;
+    for (size_t b = 0;;) {
+        const size_t e = pump_line.find(',', b);
+        pump.push_back(pump_line.substr(b, e == string::npos ? string::npos : e - b));
+        if (e == string::npos) break;
+        b = e + 1;
+    }
+    cout << regexp_str << endl;
+    Regexp* regexp = Regexp::parse_regexp(regexp_str);
+    bool is_mfa = true;
+    Automata* automata = regexp->compile(is_mfa, false, false, true, false);
+    MFA* mfa = is_mfa ? static_cast<MFA*>(automata) : nullptr;
+    std::cerr << "diploma: -bnf / -reverse curves are not written in this build (regex/bnf.cpp not restated)\n";
+    std::ofstream result_file(dir + "diploma_results.txt", std::ofstream::out | std::ofstream::trunc);
+    const char* fresh_env = std::getenv("DIPLOMA_FRESH_PREFIX");
+    const bool fresh = fresh_env && fresh_env[0] == '1';
+    const size_t len_limit = size_t(INT32_MAX / 10), device_limit = 0x00ffffffu;
+    long long pump_size = 500;
+    int round = 0;
+    string grown = prefix;
+    for (size_t len = prefix.size() + (size_t)pump_size + suffix.size(); len < len_limit;) {
+        const string input = (fresh ? prefix : grown) + pumped_string((int)pump_size, pump) + suffix;
+        grown = input;
+        len = input.size();
+        pump_size += pump_size;
+        if (len > device_limit) break;
+        const auto t0 = std::chrono::steady_clock::now();
+        if (mfa) mfa->match(input); else automata->match(input);
+        const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (seconds < 1) result_file << len << " " << seconds << endl;
+        if (seconds >= 0.5) break;
+        if (++round % 10 == 0) pump_size *= 2;
+    }
 }

@@ -1,5 +1,6 @@
 // `diploma` command line (reference main.cpp:9-87).
 //   diploma -match [-bnf] [-reverse] [-ssnf] [-all] [-log]    regex token, then string tokens until `exit`
+//   diploma -match N                                          timing series over test/example_N (example_runner.cpp)
 //   diploma -dump  [-thompson|-glushkov|-mfa]                 regex token -> automaton image as text
 //   diploma -match-file <gt|mfa> <file>                       matchers/match_mfa.cpp counterparts
 #include <algorithm>
@@ -84,9 +85,8 @@ int main(int argc, char* argv[]) {
         }
         if (argc > 1 && std::strcmp(argv[1], "-match") == 0) {
             if (argc > 2 && argv[2][0] != '-') {
-                std::cerr << "diploma: the pumped-string timing harness (-match N, matchers/example_runner.cpp) is "
-                             "provided by bench.py in this build\n";
-                return 2;
+                run_configuration_examples(argv[2]);      // main.cpp:11-13: growth curve of test/example_N
+                return 0;
             }
             bool bnf = false, reverse = false, ssnf = false, use_log = false;
             set<string> flags;

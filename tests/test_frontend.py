@@ -52,3 +52,10 @@ def test_dot_side_effect(tmp_path):
     run(["-dump"], "({a*}:1&1)*\n", tmp_path)
     dot = (tmp_path / "mfa.dot").read_text()
     assert dot.startswith("digraph g {") and "0 -> 1 [label=\"a/o1/\"]" in dot and "0 -> 3 [label=\"ε/\"]" in dot
+
+
+def test_example_runner_without_files(tmp_path):
+    """`./diploma -match N` with no test/example_N below the working directory: like the reference
+    (example_runner.cpp:93) it does nothing and exits normally -- and needs no GPU for that."""
+    p = subprocess.run([DIPLOMA, "-match", "7"], capture_output=True, text=True, cwd=tmp_path)
+    assert p.returncode == 0 and p.stdout == "" and not (tmp_path / "test").exists()

@@ -81,6 +81,40 @@ def test_cli_match_contract(tmp_path):
         assert p.stdout == expect, name
 
 
+def test_cli_example_runner(tmp_path):
+    """`./diploma -match N` (main.cpp:11-13, matchers/example_runner.cpp:84-151): "len seconds" lines in
+    test/example_N/diploma_results.txt, lengths following the reference's schedule (pump size 500, doubling per
+    round and once more every tenth round, prefix accumulating the previous string)."""
+    import subprocess
+    from mfa_amd import corpus
+    diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
+    for ex in (1, 5):
+        regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+        d = tmp_path / "test" / ("example_%d" % ex)
+        d.mkdir(parents=True)
+        (d / "regexp.txt").write_text(regex + "\nunused-python-regex\n")
+        (d / "pump.txt").write_text(",".join(pump) + "\n" + suffix + "\n" + prefix)
+        p = subprocess.run([diploma, "-match", str(ex)], capture_output=True, text=True, cwd=tmp_path, timeout=600)
+        assert p.returncode == 0, p.stderr
+        assert p.stdout.splitlines()[0] == regex
+        lines = (d / "diploma_results.txt").read_text().split("\n")
+        assert lines[-1] == "" and len(lines) > 10
+        want, grown, size, rnd = [], prefix, 500, 0
+        while True:
+            grown = grown + corpus.pumped_string(size, pump) + suffix
+            size += size
+            if len(grown) > 0x00ffffff:
+                break
+            want.append(len(grown))
+            rnd += 1
+            if rnd % 10 == 0:
+                size *= 2
+        got = [ln.split() for ln in lines[:-1]]
+        assert [int(g[0]) for g in got] == want[:len(got)], ex
+        assert all(0.0 <= float(g[1]) < 1.0 for g in got)
+        assert len(got) == len(want) or float(got[-1][1]) >= 0.5       # the series ends at the device limit or at the first slow match
+
+
 def _structured_strings(ex, rng, count, max_len):
     """Attack-like inputs with long runs: pumped strings of random size with a few bytes flipped, and
     concatenations of runs -- what run acceleration jumps over."""
