@@ -88,19 +88,32 @@ __device__ __forceinline__ uint32_t mismatch_mask16(uint4 d, uint32_t c) {
     return nz4(d.x ^ cc) | (nz4(d.y ^ cc) << 4) | (nz4(d.z ^ cc) << 8) | (nz4(d.w ^ cc) << 12);
 }
 
-// Register-only: smallest q in 1..8 such that the bytes of the current block from scan index i to the
-// end of the block (in scan direction) are q-periodic, with at least two periods visible; 0 if none.
+// 16 bytes starting at byte s (0..16) of the 32 bytes a0..a3 (little endian)
+__device__ __forceinline__ void window16(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, uint32_t s, uint64_t& lo, uint64_t& hi) {
+    if (s >= 8u) { a0 = a1; a1 = a2; a2 = a3; s -= 8u; }
+    if (s >= 8u) { a0 = a1; a1 = a2; s -= 8u; }              // s == 16
+    if (s) { lo = (a0 >> (8u * s)) | (a1 << (64u - 8u * s)); hi = (a1 >> (8u * s)) | (a2 << (64u - 8u * s)); }
+    else { lo = a0; hi = a1; }
+}
+
+// Register-only: smallest q in 1..8 such that the next nb bytes in scan order, starting at scan index i, are
+// q-periodic with at least two periods visible; 0 if none.  nb = 16 when the block that follows in scan order
+// has been prefetched (the window then spans both register blocks), else the bytes left in the current block.
 template <bool REV>
-__device__ __forceinline__ uint32_t block_period(const Input& in, uint32_t i, uint32_t& rest) {
+__device__ __forceinline__ uint32_t block_period(const Input& in, uint32_t i, uint32_t& nb) {
     const uint32_t o = (uint32_t)scan_addr<REV>(in, i) & 15u;
-    rest = REV ? o + 1u : 16u - o;
-    uint64_t lo = ((uint64_t)in.w1 << 32) | in.w0, hi = ((uint64_t)in.w3 << 32) | in.w2;
-    if (!REV && o) {                                     // drop the o bytes before i
-        if (o >= 8u) { lo = hi >> (8u * (o - 8u)); hi = 0; }
-        else { lo = (lo >> (8u * o)) | (hi << (64u - 8u * o)); hi >>= 8u * o; }
+    const uint64_t w_lo = ((uint64_t)in.w1 << 32) | in.w0, w_hi = ((uint64_t)in.w3 << 32) | in.w2;
+    const uint64_t p_lo = ((uint64_t)in.p1 << 32) | in.p0, p_hi = ((uint64_t)in.p3 << 32) | in.p2;
+    const bool ahead = in.pblk == (REV ? in.blk - 16u : in.blk + 16u);
+    uint64_t lo, hi;
+    if (REV) {                                           // the bytes that count end at offset o of the current block
+        if (ahead) { window16(p_lo, p_hi, w_lo, w_hi, o + 1u, lo, hi); nb = 16u; }
+        else { lo = w_lo; hi = w_hi; nb = o + 1u; }        // low nb bytes of the block
+    } else {                                             // ... they start at offset o
+        window16(w_lo, w_hi, ahead ? p_lo : 0, ahead ? p_hi : 0, o, lo, hi);
+        nb = ahead ? 16u : 16u - o;
     }
-    const uint32_t nb = rest;                            // bytes 0..nb-1 of (hi:lo) are the ones that count
-    for (uint32_t q = 1; q <= 8u && 2u * q <= nb; q++) {
+    for (uint32_t q = 1; q <= 8u && 2u * q <= nb; q++) {   // bytes 0..nb-1 of (hi:lo) are the ones that count
         uint64_t slo, shi;                               // (hi:lo) >> 8q
         if (q == 8u) { slo = hi; shi = 0; }
         else { slo = (lo >> (8u * q)) | (hi << (64u - 8u * q)); shi = hi >> (8u * q); }

@@ -23,7 +23,7 @@ extern char** environ;
 
 namespace mfa {
 
-static const char* kGeneratorVersion = "jit-45";
+static const char* kGeneratorVersion = "jit-47";
 
 static std::string cache_dir() {
     if (const char* e = getenv("MFA_JIT_CACHE")) return e;
@@ -51,7 +51,7 @@ static std::string image_key(const HostImage& img) {
     uint64_t h = 1469598103934665603ull;
     h = fnv1a(kGeneratorVersion, strlen(kGeneratorVersion), h);
     if (stats_build()) h = fnv1a("stats", 5, h);
-    for (const char* k : {"MFA_GEN_SCAN_DEPTH", "MFA_GEN_LB2_WORDS", "MFA_GEN_LDS_BUDGET", "MFA_GEN_PROBE_PERIODS"})
+    for (const char* k : {"MFA_GEN_SCAN_DEPTH", "MFA_GEN_LB2_WORDS", "MFA_GEN_LDS_BUDGET", "MFA_GEN_PROBE_PERIODS", "MFA_GEN_LOOK_EVERY"})
         if (const char* e = getenv(k)) h = fnv1a(e, strlen(e), fnv1a(k, strlen(k), h));
     h = fnv1a(&img.h, sizeof img.h, h);
     h = fnv1a(img.edge_begin.data(), img.edge_begin.size() * 4, h);

@@ -386,7 +386,7 @@ struct Gen {
     std::string run() {
         const uint32_t N = g.h.n_nodes;
         std::vector<std::string> words = slot_words();
-        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 8) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
+        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_LOOK_EVERY " << knob("MFA_GEN_LOOK_EVERY", 2) << "u\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 8) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
         o << "\n#define REV " << (rev ? "true" : "false") << "\n#define N_WORDS " << words.size() << "\n#define N_KEYS " << (N - 1) << "\n\n";
         const bool huge = jit_slot_registers(g) > 272;
         const uint32_t lanes = huge ? huge_lanes((uint32_t)words.size()) : 64u;
@@ -529,10 +529,10 @@ struct Gen {
              "    uint32_t q = 0u;\n"
              "    const bool ep_busy = __any(phase != 0u);      // probes run in epochs: all lanes that probe do it in the same iterations\n"
              "    if (accel && active && !final_pass && phase == 0u && i >= probe_at && !ep_busy) {\n"
-             "      uint32_t rest;\n"
-             "      q = block_period<REV>(in, i, rest);\n"
-             "      probe_at = i + rest;                      // next look: first byte of the next block\n"
-             "      if (rest < 8u) q = 0u;\n"
+             "      uint32_t nb;\n"
+             "      q = block_period<REV>(in, i, nb);\n"
+             "      probe_at = i + (nb < MFA_LOOK_EVERY ? nb : MFA_LOOK_EVERY);      // next look if nothing comes of this one\n"
+             "      if (nb < 8u) q = 0u;\n"
              "    }\n"
              "    bool need_scan = q != 0u && !(in.per_q == q && in.per_lo <= i && i < in.per_hi);\n"
              "    const unsigned long long tm0 = stats ? clock64() : 0;\n"
