@@ -317,18 +317,24 @@ __device__ __forceinline__ bool coop_mem_equal(const uint8_t* bytes, uint64_t pa
     const uint8_t* b = bytes + pb;
     const uint32_t nblk = l >> 4;
     constexpr int D = MFA_SCAN_DEPTH;
-    for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
-        uint4 x[D], y[D];
+    if (nblk <= 64u) {                                   // up to 1 KiB: one block per lane
+        uint4 x = make_uint4(0, 0, 0, 0), y = x;
+        if (lane < nblk) { __builtin_memcpy(&x, a + 16u * lane, 16); __builtin_memcpy(&y, b + 16u * lane, 16); }
+        if (__any(((x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w)) != 0u)) return false;
+    } else {
+        for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
+            uint4 x[D], y[D];
 #pragma unroll
-        for (int k = 0; k < D; k++) {
-            const uint32_t t = t0 + 64u * k + lane;
-            x[k] = y[k] = make_uint4(0, 0, 0, 0);
-            if (t < nblk) { __builtin_memcpy(&x[k], a + 16u * t, 16); __builtin_memcpy(&y[k], b + 16u * t, 16); }
+            for (int k = 0; k < D; k++) {
+                // lanes beyond the last block reload it: no branch around the loads, all 2 D of them are in flight together
+                const uint32_t t = t0 + 64u * k + lane, tc = t < nblk ? t : nblk - 1u;
+                __builtin_memcpy(&x[k], a + 16u * tc, 16); __builtin_memcpy(&y[k], b + 16u * tc, 16);
+            }
+            bool diff = false;
+#pragma unroll
+            for (int k = 0; k < D; k++) diff = diff || ((x[k].x ^ y[k].x) | (x[k].y ^ y[k].y) | (x[k].z ^ y[k].z) | (x[k].w ^ y[k].w)) != 0u;
+            if (__any(diff)) return false;
         }
-        bool diff = false;
-#pragma unroll
-        for (int k = 0; k < D; k++) diff = diff || ((x[k].x ^ y[k].x) | (x[k].y ^ y[k].y) | (x[k].z ^ y[k].z) | (x[k].w ^ y[k].w)) != 0u;
-        if (__any(diff)) return false;
     }
     const uint32_t j = 16u * nblk + lane;
     return !__any(lane < 16u && j < l && a[j] != b[j]);
