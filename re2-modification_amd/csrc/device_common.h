@@ -213,6 +213,37 @@ __device__ __forceinline__ uint32_t nz16(uint4 d) {                     // bit k
     return nz4(d.x) | (nz4(d.y) << 4) | (nz4(d.z) << 8) | (nz4(d.w) << 12);
 }
 
+// the whole blocks of a run: 16 * (index of the first block holding another byte) + the offset of that byte, or ~0.
+// One register block per load (nothing to compare with but the run's byte).
+template <int D>
+__device__ __forceinline__ uint32_t run_blocks_fwd(const uint8_t* p, uint32_t nblk, uint32_t cc, uint32_t lane) {
+    for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
+        uint4 x[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const uint32_t t = t0 + 64u * k + lane;
+            x[k] = make_uint4(0, 0, 0, 0);
+            if (t < nblk) __builtin_memcpy(&x[k], p + 16u * t, 16);
+        }
+        bool any_diff = false;
+#pragma unroll
+        for (int k = 0; k < D; k++)
+            any_diff = any_diff || (t0 + 64u * k + lane < nblk && ((x[k].x ^ cc) | (x[k].y ^ cc) | (x[k].z ^ cc) | (x[k].w ^ cc)) != 0u);
+        if (__any(any_diff)) {
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const uint32_t m = t0 + 64u * k + lane < nblk ? nz16(make_uint4(x[k].x ^ cc, x[k].y ^ cc, x[k].z ^ cc, x[k].w ^ cc)) : 0u;
+                const unsigned long long b = __ballot(m != 0u);
+                if (b) {
+                    const int L = __builtin_ctzll(b);
+                    return 16u * (t0 + 64u * k + (uint32_t)L) + (uint32_t)__builtin_ctz(__shfl(m, L));
+                }
+            }
+        }
+    }
+    return ~0u;
+}
+
 __device__ __forceinline__ uint32_t coop_period_end_fwd(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0,
                                                         uint32_t q, uint32_t lane) {
     if (i0 + q >= len) return len;
@@ -221,6 +252,13 @@ __device__ __forceinline__ uint32_t coop_period_end_fwd(const uint8_t* bytes, ui
     const uint32_t nblk = (last - i0) >> 4;              // whole 16-byte blocks
     constexpr int D = MFA_SCAN_DEPTH;                    // 16-byte blocks per lane in flight: D KiB per wave and trip
     const uint32_t cc = (uint32_t)p[i0] * 0x01010101u;   // q == 1: every byte must equal the first one
+    if (q == 1u) {                                       // byte j differs from the run's byte: the run ends at j
+        const uint32_t r = run_blocks_fwd<MFA_SCAN_DEPTH>(p + i0, nblk, cc, lane);
+        if (r != ~0u) return i0 + r;
+        const uint32_t j = i0 + 16u * nblk + lane;       // fewer than 17 positions left
+        const unsigned long long b1 = __ballot(lane < 17u && j < len && p[j] != (uint8_t)cc);
+        return b1 ? i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b1) : len;
+    }
     for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
         uint4 x[D], y[D];
 #pragma unroll
@@ -229,8 +267,7 @@ __device__ __forceinline__ uint32_t coop_period_end_fwd(const uint8_t* bytes, ui
             x[k] = y[k] = make_uint4(0, 0, 0, 0);
             if (t < nblk) {
                 __builtin_memcpy(&x[k], p + i0 + 16u * t, 16);
-                if (q == 1u) y[k] = make_uint4(cc, cc, cc, cc);
-                else __builtin_memcpy(&y[k], p + i0 + 16u * t + q, 16);
+                __builtin_memcpy(&y[k], p + i0 + 16u * t + q, 16);
             }
         }
         bool any_diff = false;
@@ -243,17 +280,13 @@ __device__ __forceinline__ uint32_t coop_period_end_fwd(const uint8_t* bytes, ui
                 const unsigned long long b = __ballot(m != 0u);
                 if (b) {
                     const int L = __builtin_ctzll(b);
-                    // q > 1: byte j differs from byte j+q, the region ends at j+q; q == 1: byte j differs from the run's byte, it ends at j
-                    return i0 + 16u * (t0 + 64u * k + (uint32_t)L) + (uint32_t)__builtin_ctz(__shfl(m, L)) + (q == 1u ? 0u : q);
+                    // byte j differs from byte j+q, the region ends at j+q
+                    return i0 + 16u * (t0 + 64u * k + (uint32_t)L) + (uint32_t)__builtin_ctz(__shfl(m, L)) + q;
                 }
             }
         }
     }
-    const uint32_t j = i0 + 16u * nblk + lane;           // fewer than 16 (q == 1: 17) positions left
-    if (q == 1u) {                                       // the blocks checked bytes against the run's byte: so does the tail
-        const unsigned long long b1 = __ballot(lane < 17u && j < len && p[j] != (uint8_t)cc);
-        return b1 ? i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b1) : len;
-    }
+    const uint32_t j = i0 + 16u * nblk + lane;           // fewer than 16 positions left
     const bool bad = lane < 16u && j < last && p[j] != p[j + q];
     const unsigned long long b = __ballot(bad);
     if (b) return i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b) + q;
