@@ -142,7 +142,6 @@ int launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_of
     hipError_t e = hipMemsetAsync(ds.d_counter, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
     uint64_t grid = (uint64_t)ds.n_cus * ds.jit_waves_per_cu, want = (n + ds.jit_lanes - 1) / ds.jit_lanes;
-    if (const char* spl = getenv("MFA_STRINGS_PER_LANE")) { const uint64_t k = (uint64_t)atoi(spl); if (k > 1) want = (want + k - 1) / k; }
     if (grid > want) grid = want;
     if (grid == 0) grid = 1;
     const char* ae = getenv("MFA_ACCEL");

@@ -633,8 +633,9 @@ struct Gen {
         o << "      }\n    }\n  }\n";
         o << "  if (stats) {\n    if (lane == 0) { atomicAdd(&stats[0], st_iter); atomicAdd(&stats[1], st_dual); atomicAdd(&stats[6], tm_scan); atomicAdd(&stats[7], tm_plain);\n"
              "      atomicAdd(&stats[8], tm_dual); atomicAdd(&stats[9], (unsigned long long)clock64() - tm_total); }\n"
-             "    atomicAdd(&stats[2], st_skip); atomicAdd(&stats[3], st_probe); atomicAdd(&stats[4], st_hit); atomicAdd(&stats[5], st_scan);\n"
-             "    atomicAdd(&stats[10], st_f_unst); atomicAdd(&stats[11], st_f_dual); atomicAdd(&stats[12], st_f_room);\n  }\n}\n";
+             "    if (lane < LANES) {                             // lanes that never carry a string hold no meaningful counts\n"
+             "      atomicAdd(&stats[2], st_skip); atomicAdd(&stats[3], st_probe); atomicAdd(&stats[4], st_hit); atomicAdd(&stats[5], st_scan);\n"
+             "      atomicAdd(&stats[10], st_f_unst); atomicAdd(&stats[11], st_f_dual); atomicAdd(&stats[12], st_f_room);\n    }\n  }\n}\n";
         (void)N;
         return o.str();
     }
