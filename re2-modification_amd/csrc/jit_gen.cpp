@@ -522,6 +522,7 @@ struct Gen {
         for (const auto& w : words)
             o << "              c." << w << " = " << (w == "P" + num(g.h.start) ? "0u" : (w[0] == 'P' ? "MFA_EMPTY" : "0u")) << ";\n";
         o << "            }\n          }\n        }\n      }\n    }\n    if (!__any(active)) break;\n    st_iter++;\n";
+        o << "    const uint32_t tr_i = i, tr_phase = phase, tr_pp = pp, tr_nper = nper; const bool tr_active = active;   // MFA_STATS builds: trace of the first strings\n";
         o << "    const bool final_pass = (i == len);\n    uint32_t ch = 0x100u;\n"
              "    if (active && !final_pass) ch = stream_byte<REV>(in, i);\n";
         // decide whether this lane starts a probe: it must sit in a long run of equal bytes
@@ -625,6 +626,10 @@ struct Gen {
              "              if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
              "              probe_at = i + 1u + (fails ? 0u : backoff);\n"
              "            }\n          }\n        }\n      }\n    }\n";
+        o << "    if (stats && tr_active && sid < 4u && st_steps < 8192u) {\n"
+             "      uint32_t* tr = (uint32_t*)(stats + 16) + ((1u << 20) - 65536u) + (uint32_t)sid * 16384u + 2u * st_steps;\n"
+             "      tr[0] = tr_i; tr[1] = tr_phase | (q << 4) | (tr_pp << 8) | (tr_nper << 16) | ((uint32_t)__any(tr_phase == 2u) << 24) | 0x80000000u;\n"
+             "    }\n";
         o << "    if (active) {\n      const bool done = accept || final_pass || !any_next;\n      i++;\n"
              "      st_steps++;\n      if (done) { results[sid] = accept ? 1 : 0; active = false; phase = 0u;\n"
              "        if (stats && sid < (1u << 20)) ((uint32_t*)(stats + 16))[sid] = st_steps;\n        st_steps = 0;\n";
