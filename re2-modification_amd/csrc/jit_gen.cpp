@@ -340,9 +340,17 @@ struct Gen {
     // all of A, then B in node order, then C in node order.
     void emit_step_chunked() {
         const uint32_t N = g.h.n_nodes;
-        const char* sig = "(uint32_t* cur_mem, uint32_t* nxt_mem, Input& in, const U i, const U len, const uint32_t ch, const bool final_pass,\n"
-                          "    bool& accept, bool& any_next, tb_t& TB, const bool active)";
-        const char* pre = "  SlotSet<U> c(cur_mem); NextSet<U> n(nxt_mem); (void)c; (void)n; (void)in; (void)ch; (void)any_next;\n";
+        const char* sig = "(uint32_t* cur_mem, uint32_t* nxt_mem, Input& in_arg, const U i, const U len, const uint32_t ch, const bool final_pass,\n"
+                          "    bool& accept_arg, bool& any_next_arg, tb_t& TB_arg, const bool active)";
+        // The slot sets and the input state are reached through the file-scope LDS arrays, not through the pointer
+        // and reference parameters: only then does the compiler know the address space and emit DS instructions
+        // (through generic pointers every slot access was a FLAT instruction: 4 200 of them per step).
+        const char* pre = "  const uint32_t hl_lane = threadIdx.x & 63u, hl_col = hl_lane < LANES ? hl_lane : LANES;\n"
+                          "  uint32_t* const cm = huge_lds + hl_col; uint32_t* const nm = cm + 2 * N_WORDS * PSTRIDE; (void)cur_mem; (void)nxt_mem;\n"
+                          "  Input& in = huge_in[hl_col]; (void)in_arg;\n"
+                          "  SlotSet<U> c(cm); NextSet<U> n(nm); (void)c; (void)n; (void)in; (void)ch;\n"
+                          "  bool accept = accept_arg, any_next = any_next_arg; tb_t TB = TB_arg;      // worked on in registers, written back at the end\n";
+        const char* post = "  accept_arg = accept; any_next_arg = any_next; TB_arg = TB;\n}\n\n";
         std::vector<std::string> calls;
         auto begin_fn = [&](const std::string& name) {
             o << "template <class U>\n__device__ __attribute__((noinline)) void " << name << sig << " {\n" << pre;
@@ -350,7 +358,7 @@ struct Gen {
         };
         begin_fn("step_a");
         for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) { emit_classify(n); emit_phase_a(n); }
-        o << "}\n\n";
+        o << post;
         int chunk = 0;
         uint32_t budget = 0;
         bool open = false;
@@ -360,9 +368,9 @@ struct Gen {
             emit_classify(n);
             emit_phase_b(n);
             budget += deg(n);
-            if (budget >= 24) { o << "}\n\n"; open = false; }
+            if (budget >= 24) { o << post; open = false; }
         }
-        if (open) { o << "}\n\n"; open = false; }
+        if (open) { o << post; open = false; }
         chunk = 0;
         for (uint32_t n = 0; n < N; n++) {
             if (is_finish(n) || !has_phase_c(n)) continue;
@@ -370,12 +378,12 @@ struct Gen {
             emit_classify(n);
             emit_phase_c(n);
             budget += deg(n);
-            if (budget >= 24) { o << "}\n\n"; open = false; }
+            if (budget >= 24) { o << post; open = false; }
         }
-        if (open) { o << "}\n\n"; open = false; }
+        if (open) { o << post; open = false; }
         begin_fn("step_end");
         emit_end();
-        o << "}\n\n";
+        o << post;
         o << "template <class U>\n__device__ __forceinline__ void mfa_step(SlotSet<U>&, Input& in, const U i, const U len, const uint32_t ch,\n"
              "                                         const bool final_pass, bool& accept, bool& any_next, tb_t& TB, uint32_t* cur_mem,\n"
              "                                         uint32_t* nxt_mem, const bool active) {\n";
@@ -443,6 +451,7 @@ struct Gen {
             o << " {}\n};\n";
         } else reg_struct("NextSet", "Dual");
         o << "\n";
+        if (huge) o << "__shared__ uint32_t huge_lds[7 * N_WORDS * PSTRIDE];      // cur, next (v and d each), SA, SB, SD\n__shared__ Input huge_in[LANES + 1];\n\n";
         if (huge) emit_step_chunked(); else emit_step();
         // ---- kernel
         // small automata: ask for two waves per SIMD (<= 128 VGPRs); the plain step needs far fewer, only the dual
@@ -456,7 +465,7 @@ struct Gen {
         o << "  unsigned long long tm_scan = 0, tm_plain = 0, tm_dual = 0, tm_total = stats ? clock64() : 0;\n";
         o << "  const uint32_t lane = threadIdx.x & 63u;\n";
         o << "  const uint32_t col = lane < LANES ? lane : LANES;     // column of this lane in the LDS images (idle lanes share one)\n";
-        o << "#if HUGE\n  __shared__ uint32_t huge_lds[7 * N_WORDS * PSTRIDE];\n  uint32_t* const cur_mem = huge_lds + col;\n"
+        o << "#if HUGE\n  uint32_t* const cur_mem = huge_lds + col;\n"
              "  uint32_t* const nxt_mem = cur_mem + 2 * N_WORDS * PSTRIDE;\n"
              "#elif NEXT_IN_LDS\n  __shared__ uint32_t nxt_lds[2 * (N_WORDS - N_KEYS) * PSTRIDE];\n  uint32_t* const cur_mem = nullptr;\n  uint32_t* const nxt_mem = nxt_lds + col;\n"
              "#else\n  uint32_t* const cur_mem = nullptr;\n  uint32_t* const nxt_mem = nullptr;\n#endif\n";
@@ -497,7 +506,8 @@ struct Gen {
                  "#define SD_RD(k) ((int32_t)SDm[(k) * 64])\n#define SD_WR(k, v) (SDm[(k) * 64] = (uint32_t)(v))\n"
                  "#define SB_RD(k) (SBm[(k) * 64])\n#define SB_WR(k, v) (SBm[(k) * 64] = (v))\n";
         }
-        o << "  Input in; in.bytes = bytes; in.total16 = (offsets[n] + 15u) & ~(uint64_t)15; input_reset(in, 0, 0);\n";
+        o << "#if HUGE\n  Input& in = huge_in[col];\n#else\n  Input in;\n#endif\n";
+        o << "  in.bytes = bytes; in.total16 = (offsets[n] + 15u) & ~(uint64_t)15; input_reset(in, 0, 0);\n";
         o << "  in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;\n";
         o << "  bool active = false, exhausted = false, accept = false;\n  uint32_t i = 0, len = 0; uint64_t sid = 0;\n";
         o << "  // run acceleration: phase 0 idle, 1 = pp plain steps after saving the slots, 2 = pp dual steps\n";
