@@ -28,6 +28,9 @@
 #include <cstring>
 
 #include "mfa_internal.h"
+#ifndef MFA_DFA_LINE
+#define MFA_DFA_LINE 128
+#endif
 #include "device_common.h"
 
 namespace mfa {
@@ -379,7 +382,9 @@ dfa_walk_kernel(const uint16_t* __restrict__ trans, const uint8_t* __restrict__ 
 }
 
 // ---- tiled table walk -----------------------------------------------------------------------------
-// Same walk, input staged through LDS so that HBM is read in whole 128-byte lines: a wave owns 64
+// Same walk, input staged through LDS so that HBM is read in whole 128-byte lines (MFA_DFA_LINE; 64-byte
+// rows double the resident waves but measured 3.7 against 4.55 TB/s; a second table stepping two bytes per
+// dependent read -- n_states * classes^2 entries -- measured 4.4: the walk is not bound by that chain): a wave owns 64
 // strings; each round, groups of 8 lanes fetch one 128-byte line of one string (8 x 16 B, a single
 // contiguous segment per group), the 64 lines are written to a padded LDS tile, and every lane then
 // reads its own string's line back with ds_read_b128.  The pad (144-byte row stride) keeps the 16
@@ -395,7 +400,10 @@ struct DfaPacked {
     uint32_t accept_mask;    // bit s = state s accepts
 };
 
-static constexpr uint32_t kTileRow = 144;    // bytes per string row in the LDS tile (128 + 16 pad)
+static constexpr uint32_t kLine = MFA_DFA_LINE;          // bytes of a string staged per round (one row of the tile)
+static constexpr uint32_t kTileRow = kLine + 16;         // row stride in the LDS tile: the pad keeps ds_read_b128 groups on distinct banks
+static constexpr uint32_t kLineLanes = kLine / 16;       // lanes that fetch one row, 16 bytes each
+static constexpr uint32_t kFetches = kLineLanes;         // 64 / kLineLanes strings per load instruction -> kLineLanes instructions per round
 
 template <bool REV, bool PACKED, int NLIT>
 __global__ void __launch_bounds__(256)
@@ -427,33 +435,54 @@ dfa_tiled_kernel(DfaPacked pk, const uint16_t* __restrict__ trans, const uint8_t
         const uint64_t b = have ? offsets[sid] : 0, e = have ? offsets[sid + 1] : 0;
         uint64_t p = REV ? e : b;                 // forward: next byte to consume; reverse: one past it
         uint32_t st = PACKED ? 1u : kDfaRow;      // state 1 = {start}
-        for (;;) {
-            const bool active = have && st != 0u && (REV ? p > b : p < e);
-            if (!__any(active)) break;
-            const uint64_t line = (REV ? p - 1u : p) & ~(uint64_t)127;
-            // fetch: lane group g = lane>>3 serves strings g, g+8, ..., one 128-byte line each
-            uint4 v[8];
+        bool active = have && (REV ? p > b : p < e);
+        if (__any(active)) {                      // (a wave of empty strings has nothing to read)
+        uint64_t line = (REV ? p - 1u : p) & ~(uint64_t)(kLine - 1u);
+        // fetch: lane group g = lane>>3 serves strings g, g+8, ..., one 128-byte line each
+        uint4 v[kFetches];
+        auto fetch = [&](uint64_t ln, bool act) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const int src = k * 8 + (int)(lane >> 3);
-                const uint32_t lo = __shfl((uint32_t)line, src), hi = __shfl((uint32_t)(line >> 32), src);
-                const int act = __shfl((int)active, src);
-                const uint64_t addr = (((uint64_t)hi << 32) | lo) + (lane & 7u) * 16u;
-                v[k] = (act && addr < total16) ? load16(bytes, addr) : make_uint4(0, 0, 0, 0);
+            for (int k = 0; k < (int)kFetches; k++) {
+                const int src = k * (int)(64u / kLineLanes) + (int)(lane / kLineLanes);
+                const uint32_t lo = __shfl((uint32_t)ln, src), hi = __shfl((uint32_t)(ln >> 32), src);
+                const int a = __shfl((int)act, src);
+                const uint64_t addr = (((uint64_t)hi << 32) | lo) + (lane % kLineLanes) * 16u;
+                v[k] = (a && addr < total16) ? load16(bytes, addr) : make_uint4(0, 0, 0, 0);
             }
+        };
+        fetch(line, active);
+        for (;;) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const uint32_t src = (uint32_t)k * 8u + (lane >> 3);
-                *reinterpret_cast<uint4*>(tile + src * kTileRow + (lane & 7u) * 16u) = v[k];
+            for (int k = 0; k < (int)kFetches; k++) {
+                const uint32_t src = (uint32_t)k * (64u / kLineLanes) + lane / kLineLanes;
+                *reinterpret_cast<uint4*>(tile + src * kTileRow + (lane % kLineLanes) * 16u) = v[k];
             }
             __builtin_amdgcn_wave_barrier();
+            // the next line of every string (if it has one) is requested now and arrives while this one is walked
+            const uint64_t p_next = REV ? line : line + kLine;
+            fetch((REV ? p_next - 1u : p_next) & ~(uint64_t)(kLine - 1u), active && (REV ? p_next > b : p_next < e));
             // walk this lane's line
             const uint32_t lo_b = active ? (uint32_t)((REV ? (b > line ? b - line : 0) : p - line)) : 0u;
-            const uint32_t hi_b = active ? (uint32_t)((REV ? p - line : (e - line < 128u ? e - line : 128u))) : 0u;
-            const bool full = __all(!active || (lo_b == 0u && hi_b == 128u));
+            const uint32_t hi_b = active ? (uint32_t)((REV ? p - line : (e - line < kLine ? e - line : kLine))) : 0u;
+            const bool full = __all(!active || (lo_b == 0u && hi_b == kLine));
+            if (!PACKED && full && __all(active)) {
+                // every lane walks a whole line: nothing to mask (the dead state 0 maps to itself, so a string that
+                // dies inside the line stays dead) -- three instructions per byte: extract, add, table read
 #pragma unroll 1
-            for (int q = 0; q < 8; q++) {
-                const int qq = REV ? 7 - q : q;
+                for (int q = 0; q < (int)kLineLanes; q++) {
+                    const int qq = REV ? (int)kLineLanes - 1 - q : q;
+                    const uint4 d = *reinterpret_cast<const uint4*>(tile + lane * kTileRow + (uint32_t)qq * 16u);
+                    const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                    for (int kk = 0; kk < 16; kk++) {
+                        const int k = REV ? 15 - kk : kk;
+                        st = s_next[st + ((w[k >> 2] >> (8 * (k & 3))) & 0xffu)];
+                    }
+                }
+            } else
+#pragma unroll 1
+            for (int q = 0; q < (int)kLineLanes; q++) {
+                const int qq = REV ? (int)kLineLanes - 1 - q : q;
                 const uint4 d = *reinterpret_cast<const uint4*>(tile + lane * kTileRow + (uint32_t)qq * 16u);
                 const uint32_t w[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
@@ -474,8 +503,12 @@ dfa_tiled_kernel(DfaPacked pk, const uint16_t* __restrict__ trans, const uint8_t
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (active) p = REV ? line : line + 128u;
+            if (active) p = p_next;
             if (!REV && p > e) p = e;
+            active = have && st != 0u && (REV ? p > b : p < e);
+            if (!__any(active)) break;
+            line = (REV ? p - 1u : p) & ~(uint64_t)(kLine - 1u);
+        }
         }
         if (have) results[sid] = PACKED ? (uint8_t)((pk.accept_mask >> st) & 1u) : accept_tab[st / kDfaRow];
     }
@@ -562,7 +595,10 @@ template <bool REV, bool PACKED, int NLIT>
 static int launch_dfa_tiled(const HostImage& img, DeviceState& ds, const DfaPacked& pk, const uint8_t* d_bytes,
                             const uint64_t* d_offsets, uint64_t n, uint8_t* d_results, hipStream_t s) {
     size_t lds = 4 * 64 * kTileRow + (PACKED ? 0 : (size_t)img.dfa_states * kDfaRow * sizeof(uint16_t));
-    uint64_t blocks = (n + 255) / 256, cap = (uint64_t)ds.n_cus * 4;
+    uint64_t per_cu = (160u * 1024u) / lds;                 // resident blocks a CU's LDS allows (at most 8: 32 waves)
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    uint64_t blocks = (n + 255) / 256, cap = (uint64_t)ds.n_cus * per_cu;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
     auto kern = dfa_tiled_kernel<REV, PACKED, NLIT>;
@@ -583,7 +619,7 @@ int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_byte
         const char* mode = getenv("MFA_DFA_KERNEL");                                 // "simple" selects the untiled walk
         if (!(mode && mode[0] == 's')) {
             DfaPacked pk;
-            // measured on MI355X, (a|b)*abb, 1M x 1 KiB: table in LDS 3.25 TB/s, table packed in SGPRs 2.65 TB/s,
+            // measured on MI355X, (a|b)*abb, 1M x 1 KiB: table in LDS 4.58 TB/s (3.25 when the packed form was measured: 2.65),
             // untiled 1.0 TB/s -- the LDS table is the default, "packed" selects the SGPR form
             const bool packed = mode && mode[0] == 'p' && make_packed(img, pk);
             if ((size_t)img.dfa_states * kDfaRow * 2 + 4 * 64 * kTileRow <= 64 * 1024) {
