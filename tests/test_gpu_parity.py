@@ -157,6 +157,32 @@ def test_long_runs_against_oracle(ex, mode):
         name, bad.size, len(strings[bad[0]]), strings[bad[0]][:60], want[bad[0]])
 
 
+NFA_NAMES = [a["name"] for a in MANIFEST["automata"] if a["name"].startswith("nfa_")]
+
+
+@pytest.mark.parametrize("name", NFA_NAMES)
+def test_table_walk_whole_lines(name):
+    """Memory-less automata on batches the golden strings are too short for: 256 strings of exactly 1 KiB (every
+    128-byte line of the tiled walk lies wholly inside its string: the mask-free path, forward and reversed) and a
+    ragged batch whose lines are partly outside their strings, against the CPU restatement."""
+    blob = image.blob_from_dump(oracle_lib.load_dump(name))
+    rng = np.random.default_rng(len(name) * 7919)
+    ora = oracle_lib.OracleImage(blob)
+    img = capi.Image(blob)
+    for lens in ([1024] * 256, [int(x) for x in rng.integers(0, 700, size=300)]):
+        strings = []
+        for k, ln in enumerate(lens):
+            t = bytes(rng.choice(list(b"ab" if k % 4 else b"abc."), size=ln).tolist())
+            if k % 3 == 0 and ln >= 3:
+                t = t[:-3] + b"abb"
+            strings.append(t)
+        want = ora.match(strings)
+        got = gpu_match(img, strings)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "%s: %d mismatches, first len %d want %d" % (name, bad.size, len(strings[bad[0]]), want[bad[0]])
+        assert img.info()["last_kernel"] == capi.KERNEL_TABLE
+
+
 def _periodic_fuzz(rng, count, max_len, alphabet=b"abc"):
     """Concatenations of periodic regions (period 1..8) with occasional single-byte damage: the inputs run /
     period acceleration keys on, with region boundaries and damage at random phases."""
