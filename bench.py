@@ -71,7 +71,7 @@ def cpu_baseline(shards, gpu_results, budget_strings=8, cap=32768):
             f = p.stdout.split()
             n_str += int(f[0]); tot_bytes += int(f[1]); tot_sec += float(f[2]); acc_cpu += int(f[3])
         # wider parity check with the CPU restatement (fast): the first PARITY_N strings of every example
-        checked, mism = 0, 0
+        checked, mism, port_bytes, port_sec = 0, 0, 0, 0.0
         if os.path.exists(cli):
             for ex, sh in shards.items():
                 sample = [s for s in sh["sample"] if len(s) <= 32768]
@@ -79,9 +79,12 @@ def cpu_baseline(shards, gpu_results, budget_strings=8, cap=32768):
                 blob_path = os.path.join(tmp, "p%d.blob" % ex)
                 with open(blob_path, "wb") as f:
                     f.write(sh["blob"])
+                t0 = time.perf_counter()
                 p = subprocess.run([cli, "match", blob_path], input=b"".join(s + b"\n" for s in sample), capture_output=True, cwd=tmp)
                 if p.returncode != 0:
                     continue
+                port_sec += time.perf_counter() - t0
+                port_bytes += sum(len(s) for s in sample)
                 want = [int(x) for x in p.stdout.split()]
                 got = [int(gpu_results[ex][k]) for k in idx]
                 checked += len(want)
@@ -93,7 +96,10 @@ def cpu_baseline(shards, gpu_results, budget_strings=8, cap=32768):
                 n_str, budget_strings, cap // 1024, tot_bytes, tot_sec),
             # the same strings were matched on the GPU in the timed region: the accept counts must agree
             "accepted": acc_cpu, "accepted_gpu": acc_gpu, "parity": acc_cpu == acc_gpu and mism == 0,
-            "parity_restatement": {"strings": checked, "mismatches": mism}}
+            "parity_restatement": {"strings": checked, "mismatches": mism},
+            # the CPU restatement (oracle/mfa_oracle.c, -O2, one thread) on the parity sample, process start included
+            "restatement": {"value": port_bytes / port_sec / 1e9 if port_sec > 0 else None, "unit": "GB/s", "cores": 1, "kind": "port",
+                            "sample": "%d strings, %d bytes, %.2f s" % (checked, port_bytes, port_sec)}}
 
 
 def secondary_dfa(device, n_strings=1 << 20, length=1024):

@@ -35,6 +35,8 @@ struct Input {
     uint32_t run_lo, run_hi, run_ch;
     // cached periodic region: scan[j] == scan[j + per_q] for per_lo <= j < per_hi - per_q (per_q = 0: none)
     uint32_t per_lo, per_hi, per_q;
+    // the periodic region known before that one (a cell captured there may be read inside the current one)
+    uint32_t prev_lo, prev_hi, prev_q;
     uint32_t dual_p;        // steps per period of the dual step in flight (slope of i), 0 in plain steps
 };
 
@@ -43,6 +45,7 @@ __device__ __forceinline__ void input_reset(Input& in, uint64_t base, uint32_t l
     in.blk = ~(uint64_t)0; in.pblk = ~(uint64_t)0;
     in.run_lo = in.run_hi = 0; in.run_ch = 0x100u;
     in.per_lo = in.per_hi = 0; in.per_q = 0; in.dual_p = 0;
+    in.prev_lo = in.prev_hi = 0; in.prev_q = 0;
 }
 
 // scan index j -> byte offset (reversed automata scan the string backwards: mfa.cpp:163-166)
@@ -508,6 +511,13 @@ __device__ __forceinline__ void spans_period_bound(const Input& in, Dual i, Dual
     if (start.d != 0) (void)le(add(start, l), Dual{in.per_hi, 0}, TB);
 }
 
+// does scan[s, s+l) lie inside one of the two periodic regions the lane knows?  q = that region's period
+__device__ __forceinline__ bool span_in_region(const Input& in, uint32_t s, uint32_t l, uint32_t& q) {
+    if (in.per_q != 0u && s >= in.per_lo && s + l <= in.per_hi) { q = in.per_q; return true; }
+    if (in.prev_q != 0u && s >= in.prev_lo && s + l <= in.prev_hi) { q = in.prev_q; return true; }
+    return false;
+}
+
 // would the cell read below have to look for the end of the run of bytes at i?  (then the caller finds it
 // with the whole wave first, so that read_pre_u never scans memory from a single lane)
 __device__ __forceinline__ bool uni_needs_run(const Input& in, uint32_t i, uint32_t ch, uint32_t l, uint32_t fl) {
@@ -542,6 +552,12 @@ __device__ __forceinline__ bool read_pre_u(Input& in, U i, uint32_t ch, U start,
     const uint32_t lv = val(l), head = lv < 16u ? lv : 16u;
     if (!spans_equal<REV>(in, REV ? val(start) + (lv - head) : val(start), REV ? val(i) + (lv - head) : val(i), head)) return false;
     if (lv <= 16u) return true;
+    // two q-periodic spans (q <= 8) whose first 16 bytes agree are equal: nothing more to read.  Plain steps only
+    // (lanes in a dual period have to bound the outcome over the periods to come: spans_period_bound above).
+    if (in.dual_p == 0u) {
+        uint32_t qa = 0, qb = 0;
+        if (span_in_region(in, val(start), lv, qa) && span_in_region(in, val(i), lv, qb) && qa == qb) return true;
+    }
     need_cmp = true;
     return false;
 }

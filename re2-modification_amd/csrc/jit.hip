@@ -23,7 +23,7 @@ extern char** environ;
 
 namespace mfa {
 
-static const char* kGeneratorVersion = "jit-57";
+static const char* kGeneratorVersion = "jit-60";
 
 static std::string cache_dir() {
     if (const char* e = getenv("MFA_JIT_CACHE")) return e;

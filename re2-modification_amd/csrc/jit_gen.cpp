@@ -188,7 +188,12 @@ struct Gen {
                 o << ind << "        const int L = __builtin_ctzll(sb);\n";
                 o << ind << "        const uint32_t r = coop_period_end<REV>(in.bytes, ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L),\n";
                 o << ind << "                                               __shfl(in.len, L), __shfl(val(i), L), 1u, threadIdx.x & 63u);\n";
-                o << ind << "        if ((threadIdx.x & 63u) == (uint32_t)L) { in.run_lo = val(i); in.run_hi = r; in.run_ch = ch; }\n";
+                // a run is a periodic region too: remember it as one, so that the main loop's look does not measure it again
+                // (unless a region that reaches at least as far is already known -- a probe may be relying on it)
+                o << ind << "        if ((threadIdx.x & 63u) == (uint32_t)L) {\n"
+                  << ind << "          in.run_lo = val(i); in.run_hi = r; in.run_ch = ch;\n"
+                  << ind << "          if (!(in.per_q != 0u && in.per_lo <= val(i) && val(i) < in.per_hi && in.per_hi >= r)) { in.per_lo = val(i); in.per_hi = r; in.per_q = 1u; }\n"
+                  << ind << "        }\n";
                 o << ind << "      }\n";
                 o << ind << "    }\n";
                 o << ind << "    bool " << ok << " = false, cmp" << id << " = false;\n";
@@ -551,7 +556,10 @@ struct Gen {
              "      const int L = __builtin_ctzll(sb);\n"
              "      const uint64_t sbase = ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L);\n"
              "      const uint32_t r = coop_period_end<REV>(bytes, sbase, __shfl(len, L), __shfl(i, L), __shfl(q, L), lane);\n"
-             "      if (lane == (uint32_t)L) { in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++; }\n"
+             "      if (lane == (uint32_t)L) {\n"
+             "        if (in.per_q != 0u) { in.prev_lo = in.per_lo; in.prev_hi = in.per_hi; in.prev_q = in.per_q; }\n"
+             "        in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++;\n"
+             "      }\n"
              "    }\n"
              "    if (stats) tm_scan += clock64() - tm0;\n"
              "    if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
