@@ -334,7 +334,7 @@ def main():
         # read from inside the run); only quoted when this run is the workload they were collected on
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01i_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01j_traffic.json")) as f:
                 tj = json.load(f)
             wl = tj["workload"]
             if (wl["strings_per_example"], wl["min_len"], wl["max_len"]) == (n_per, args.min_len, args.max_len) and args.concurrent:
