@@ -90,6 +90,9 @@ int  mfa_image_specialize(mfa_image_t* img);
  * DEVICE pointers on `device` (offsets has n+1 entries; results gets n bytes, 1 =
  * accepted, 0 = rejected -- the value `cout << match` prints, match.cpp:30).
  * A string longer than MFA_MAX_STRING_BYTES is not matched: its result byte is set to 2.
+ * The kernels read the batch in whole 16-byte blocks: d_bytes must be readable up to offsets[n]
+ * rounded up to the next multiple of 16 (hipMalloc'ed buffers always are; a batch carved out of a
+ * larger buffer needs up to 15 bytes of slack behind it).  The bytes there are never interpreted.
  * Asynchronous: work is enqueued on `stream` (a hipStream_t, NULL = default
  * stream) and the call returns.  Replaces: the loop
  *     while (...) { match = automata->match(text); }      match.cpp:21-31 */
