@@ -192,8 +192,9 @@ def main():
     ap.add_argument("--max-len", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="HIP streams the ten launches of a step are spread over (longest-processing-time-first); "
+    ap.add_argument("--streams", type=int, default=0,
+                    help="HIP streams the ten launches of a step are spread over (longest-processing-time-first); 0 = try 3, 4 and 6 "
+                         "during set-up and keep the fastest; "
                          "the runtime maps streams onto four hardware queues, more streams gain nothing")
     ap.add_argument("--sequential", dest="concurrent", action="store_false",
                     help="launch the ten examples one after another on one stream instead of on ten streams")
@@ -256,25 +257,11 @@ def main():
     # long examples start at once and no stream is left with a long kernel at the end of the step
     order = list(shards)
     streams = {ex: main for ex in shards}
-    if args.concurrent and args.streams > 1:
-        for ex, sh in shards.items():
-            sh["img"].match_tensors(sh["bytes"], sh["off"], results[res_pos[ex]:res_pos[ex] + sh["n"]], stream=main)
-        torch.cuda.synchronize()
-        cost = {ex: shards[ex]["img"].last_kernel_ms(local) for ex in shards}
-        pool = [torch.cuda.Stream(device) for _ in range(min(args.streams, len(shards)))]
-        load = [0.0] * len(pool)
-        queue = [[] for _ in pool]
-        for ex in sorted(shards, key=lambda e: -cost[e]):
-            k = load.index(min(load))
-            load[k] += cost[ex]
-            queue[k].append(ex)
-            streams[ex] = pool[k]
-        order = [q[j] for j in range(max(len(q) for q in queue)) for q in queue if j < len(q)]
 
-    def step(record):
+    def launch_all(order_, streams_):
         ev_fork.record(main)
-        for ex in order:
-            sh, st = shards[ex], streams[ex]
+        for ex in order_:
+            sh, st = shards[ex], streams_[ex]
             if st is not main:
                 st.wait_event(ev_fork)
             sh["img"].match_tensors(sh["bytes"], sh["off"], results[res_pos[ex]:res_pos[ex] + sh["n"]], stream=st)
@@ -282,6 +269,40 @@ def main():
                 ev_done[ex].record(st)
                 main.wait_event(ev_done[ex])
         ev_join.record(main)
+
+    n_streams = 1
+    if args.concurrent and args.streams != 1:
+        launch_all(order, streams)                       # back to back on one stream: each example's own kernel time
+        torch.cuda.synchronize()
+        cost = {ex: shards[ex]["img"].last_kernel_ms(local) for ex in shards}
+        pool = [torch.cuda.Stream(device) for _ in range(min(max(args.streams, 6), len(shards)))]
+
+        def schedule(n):
+            load, queue, where = [0.0] * n, [[] for _ in range(n)], {}
+            for ex in sorted(shards, key=lambda e: -cost[e]):
+                k = load.index(min(load))
+                load[k] += cost[ex]
+                queue[k].append(ex)
+                where[ex] = pool[k]
+            return [q[j] for j in range(max(len(q) for q in queue)) for q in queue if j < len(q)], where
+
+        # --streams 0: the stream count is tried out (how well kernels overlap depends on which ones meet): two
+        # untimed passes per candidate, the fastest fork-to-join span wins
+        best = None
+        for n in ([args.streams] if args.streams > 1 else [3, 4, 6]):
+            cand = schedule(min(n, len(shards)))
+            spans = []
+            for _ in range(2 if args.streams < 1 else 0):
+                launch_all(*cand)
+                ev_join.synchronize()
+                spans.append(ev_fork.elapsed_time(ev_join))
+            t = min(spans) if spans else 0.0
+            if best is None or t < best[0]:
+                best = (t, n, cand)
+        n_streams, (order, streams) = best[1], best[2]
+
+    def step(record):
+        launch_all(order, streams)
         bitmap = sharding.pack_bitmap(results)
         if dist:
             dist.gather(bitmap.to(comm_dev), gathered, dst=0)      # RCCL over xGMI: the path's only exchange
@@ -334,7 +355,7 @@ def main():
         # read from inside the run); only quoted when this run is the workload they were collected on
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01j_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r01k_traffic.json")) as f:
                 tj = json.load(f)
             wl = tj["workload"]
             if (wl["strings_per_example"], wl["min_len"], wl["max_len"]) == (n_per, args.min_len, args.max_len) and args.concurrent:
@@ -355,7 +376,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "%s: 10 launches per step, one per example, %s" % (
                              "/".join(sorted({kinds[sh["img"].info()["last_kernel"]] for sh in shards.values()})),
-                             "concurrent on %d streams, longest first (duration = fork-to-join span)" % args.streams if args.concurrent else "back to back on one stream"),
+                             "concurrent on %d streams, longest first (duration = fork-to-join span)" % n_streams if args.concurrent else "back to back on one stream"),
                          "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s},
             "per_example": per_ex,
         }

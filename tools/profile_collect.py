@@ -36,7 +36,7 @@ traffic = {
                  "max_len": cfg.get("max_len", 65536), "n_gpus": bench["n_gpus"]},
     "how": "two separate rocprofv3 --pmc passes over `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary` (FETCH_SIZE, then "
            "WRITE_SIZE), summed over the %d mfa_jit_kernel dispatches of the timed step (the run's earlier %d dispatches are the untimed "
-           "calibration pass); units are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced "
+           "set-up passes: calibration and stream-count selection); units are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced "
            "reads; confirmed on dfa_tiled_kernel: 1 GiB read -> 528 695 KiB reported = 0.504x)" % (bench_n_examples, n_f - bench_n_examples),
     "fetch_size_kib": fetch, "write_size_kib": write,
     "hbm_bytes_per_step": int(2 * fetch * 1024 + write * 1024),
