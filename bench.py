@@ -377,7 +377,10 @@ def main():
                          "kernel": "%s: 10 launches per step, one per example, %s" % (
                              "/".join(sorted({kinds[sh["img"].info()["last_kernel"]] for sh in shards.values()})),
                              "concurrent on %d streams, longest first (duration = fork-to-join span)" % n_streams if args.concurrent else "back to back on one stream"),
-                         "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s},
+                         "algorithmic_bytes_per_step": alg,
+                         # mean duration of one of the step's dispatches (own start/stop events; they overlap): what a kernel trace's
+                         # per-dispatch durations of the timed steps average to (profiles/*_span_check.txt lists their sum per step)
+                         "dispatch_ms_mean": float(np.mean([np.mean(kernel_ms[ex]) for ex in shards])), "kernel_seconds_per_step": kern_s},
             "per_example": per_ex,
         }
         if not args.no_cpu_baseline and world == 1:
