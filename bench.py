@@ -1,20 +1,25 @@
 #!/usr/bin/env python3
 """Benchmark of the match path: input GB/s on the 10-example attack corpus (BASELINE.json metric).
 
-One step = one pass of the hot path over this rank's shard of the corpus: for each of the ten README
-examples (plain-mode MFA, as `./diploma -match` compiles them) one `mfa_match_batch` launch over that
-example's strings, then the result bitmap of the shard is gathered to rank 0 (RCCL when N > 1).
+One step = one pass of the hot path over this rank's shard of the mixed corpus (BASELINE configs[3]): ONE batch
+(one byte buffer, one offset array) that holds the strings of all ten README examples, example after example.
+Per step and per example: one launch of the region pre-pass (region_scan_kernel, mfa_region_scan) on the region
+stream and one launch of the example's walk kernel (mfa_match_batch_regions) on a walk stream that waits for it;
+then the result bitmap of the shard is gathered to rank 0 (RCCL when N > 1).
 Per-GPU work is fixed (weak scaling): rank r holds `--strings-per-example` strings of every example,
 `prefix + pumped_string(n, pump) [+ suffix]` with n log-uniform in [--min-len, --max-len]
 (generator: reference matchers/example_runner.cpp:15-29), generated on the device before the timed
 region, so the timed region starts with all inputs resident in HBM.
 
-Launch (N > 1):  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
-                 --master-port P bench.py --gpus N --steps K --warmup W
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh
+processes, before anything touches a GPU); under torchrun (RANK / WORLD_SIZE set) it is one of the ranks:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
 """
 import argparse
 import json
 import os
+import socket
 import subprocess
 import sys
 import tempfile
@@ -23,25 +28,59 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "re2-modification_amd"))
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
-from mfa_amd import capi, corpus, image, sharding  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PARITY_N = 48                  # strings per example whose GPU answers are re-checked on the CPU after the timed region
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+
+
+def spawn_ranks(args):
+    """`--gpus N` without a launcher: start N fresh processes, one per GPU, and wait for them.  Nothing in this process
+    has touched a GPU (counting devices does not initialise the runtime), and no process is replaced by exec."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    env = dict(os.environ)
+    if n_dev < args.gpus and env.get("MFA_BENCH_REHEARSE") != "1":
+        sys.stderr.write("bench.py: --gpus %d but %d device(s) visible; MFA_BENCH_REHEARSE=1 runs the ranks on one GPU over gloo\n"
+                         % (args.gpus, n_dev))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env.update({"WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "MFA_BENCH_SPAWNED": "1"})
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
 
 
 def load_blob(name):
+    from mfa_amd import image
     with open(os.path.join(GOLDEN, "images", name + ".dump")) as f:
         return image.blob_from_dump(f.read())
 
 
-def cpu_baseline(shards, gpu_results, budget_strings=8, cap=32768):
+# ---- CPU baseline (rank 0, N = 1 only; bounded sample) ------------------------------------------------------------
+def _oracle_time(args):
+    cli, blob_path, text = args
+    p = subprocess.run([cli, "time", blob_path], input=text, capture_output=True)
+    if p.returncode != 0:
+        return None
+    f = p.stdout.split()
+    return int(f[0]), int(f[1]), float(f[2]), int(f[3])
+
+
+def cpu_baseline(corpus, shards, gpu_results, budget_strings=8, cap=32768):
     """Time the reference itself (oracle/_ref/ref_harness: its own sources, built as it builds them, no
     -O flag, canonical allocation-order mode) on a bounded sample of the same workload; falls back to
-    our CPU restatement when the reference build is not present."""
+    our CPU restatement when the reference build is not present.  Beside it: the restatement on ALL host
+    cores (one process per core over the parity sample), core count stated."""
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     cli = os.path.join(ROOT, "oracle", "oracle_cli")
     use_ref = os.path.exists(ref)
@@ -72,7 +111,9 @@ def cpu_baseline(shards, gpu_results, budget_strings=8, cap=32768):
             n_str += int(f[0]); tot_bytes += int(f[1]); tot_sec += float(f[2]); acc_cpu += int(f[3])
         # wider parity check with the CPU restatement (fast): the first PARITY_N strings of every example
         checked, mism, port_bytes, port_sec = 0, 0, 0, 0.0
+        all_cores = None
         if os.path.exists(cli):
+            jobs = []
             for ex, sh in shards.items():
                 sample = [s for s in sh["sample"] if len(s) <= 32768]
                 idx = [k for k, s in enumerate(sh["sample"]) if len(s) <= 32768]
@@ -89,21 +130,65 @@ def cpu_baseline(shards, gpu_results, budget_strings=8, cap=32768):
                 got = [int(gpu_results[ex][k]) for k in idx]
                 checked += len(want)
                 mism += sum(1 for a, b in zip(want, got) if a != b) + abs(len(want) - len(got))
+                jobs.append((blob_path, sample))
+            # the restatement on every host core: the parity sample dealt round-robin to one process per core
+            cores = os.cpu_count() or 1
+            from concurrent.futures import ThreadPoolExecutor
+            work = []
+            for blob_path, sample in jobs:
+                for c in range(cores):
+                    part = sample[c::cores]
+                    if part:
+                        work.append((cli, blob_path, b"".join(s + b"\n" for s in part)))
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as pool:
+                done = [d for d in pool.map(_oracle_time, work) if d]
+            wall = time.perf_counter() - t0
+            if done and wall > 0:
+                all_cores = {"value": sum(d[1] for d in done) / wall / 1e9, "unit": "GB/s", "cores": cores, "kind": "port",
+                             "sample": "%d strings, %d bytes, %.2f s wall, one oracle_cli process per core (process start included)" % (
+                                 sum(d[0] for d in done), sum(d[1] for d in done), wall)}
     if tot_sec <= 0:
         return None
     return {"value": tot_bytes / tot_sec / 1e9, "unit": "GB/s", "cores": 1, "kind": "reference" if use_ref else "port",
             "sample": "%d strings (first <=%d of each example's shard with length <= %d KiB), %d bytes, %.1f s, 1 thread" % (
                 n_str, budget_strings, cap // 1024, tot_bytes, tot_sec),
+            "provenance": ("oracle/_ref/ref_harness: /root/reference's own .cpp files compiled where they lie by oracle/Makefile, no -O flag "
+                           "(as its CMakeLists builds them), bump-arena allocation-order mode" if use_ref else
+                           "oracle/oracle_cli: CPU restatement oracle/mfa_oracle.c, -O2"),
             # the same strings were matched on the GPU in the timed region: the accept counts must agree
             "accepted": acc_cpu, "accepted_gpu": acc_gpu, "parity": acc_cpu == acc_gpu and mism == 0,
             "parity_restatement": {"strings": checked, "mismatches": mism},
             # the CPU restatement (oracle/mfa_oracle.c, -O2, one thread) on the parity sample, process start included
             "restatement": {"value": port_bytes / port_sec / 1e9 if port_sec > 0 else None, "unit": "GB/s", "cores": 1, "kind": "port",
-                            "sample": "%d strings, %d bytes, %.2f s" % (checked, port_bytes, port_sec)}}
+                            "sample": "%d strings, %d bytes, %.2f s" % (checked, port_bytes, port_sec)},
+            "restatement_all_cores": all_cores}
 
 
-def secondary_dfa(device, n_strings=1 << 20, length=1024):
+# ---- secondary lines (other BASELINE configs; rank 0, N = 1 only) --------------------------------------------------
+def _timed(img, flat, off, res, device, reps=3):
+    import numpy as np
+    import torch
+    ms, rms = [], []
+    for _ in range(reps + 1):
+        img.match_tensors(flat, off, res)
+        ms.append(img.last_kernel_ms(device.index or 0))
+        rms.append(img.last_region_ms(device.index or 0))
+    torch.cuda.synchronize()
+    return float(np.mean(ms[1:])), float(np.mean(rms[1:]))
+
+
+def _oracle_sample(blob, strings, got):
+    """parity field of a secondary line: the CPU restatement on a sample of the line's own strings"""
+    import oracle_lib
+    want = oracle_lib.OracleImage(blob).match(strings)
+    bad = sum(1 for a, b in zip(want, got) if int(a) != int(b))
+    return {"strings": len(strings), "bytes": sum(len(s) for s in strings), "mismatches": bad}
+
+
+def secondary_dfa(device, capi, n_strings=1 << 20, length=1024):
     """BASELINE.json configs[1]: Thompson automaton of (a|b)*abb through the API, 1M random 1 KiB strings."""
+    import torch
     img = capi.Image(load_blob("nfa_abb_thompson"))
     g = torch.Generator(device=device); g.manual_seed(0x5EED0002)
     data = torch.randint(0, 2, (n_strings, length), generator=g, device=device, dtype=torch.uint8) + ord("a")
@@ -111,33 +196,22 @@ def secondary_dfa(device, n_strings=1 << 20, length=1024):
     flat = torch.cat([data.reshape(-1), torch.zeros(64, dtype=torch.uint8, device=device)])
     off = torch.arange(0, (n_strings + 1) * length, length, dtype=torch.int64, device=device)
     res = torch.empty(n_strings, dtype=torch.uint8, device=device)
-    ms = []
-    for _ in range(4):
-        img.match_tensors(flat, off, res)
-        ms.append(img.last_kernel_ms(device.index or 0))
-    torch.cuda.synchronize()
-    t = float(np.mean(ms[1:]))
+    t, _ = _timed(img, flat, off, res, device)
     want = (data[:, -3] == ord("a")) & (data[:, -2] == ord("b")) & (data[:, -1] == ord("b"))
     ok = bool(torch.equal(res.bool(), want))
     gbs = n_strings * length / (t * 1e-3) / 1e9
-    return {"workload": "(a|b)*abb Thompson NFA (tabulated), %d random %d-byte strings" % (n_strings, length),
-            "kernel": "dfa_walk_kernel", "kernel_ms": t, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS,
+    return {"workload": "configs[1]: (a|b)*abb Thompson NFA (tabulated), %d random %d-byte strings" % (n_strings, length),
+            "kernel": "dfa_tiled_kernel", "kernel_ms": t, "GB/s": gbs, "touched_bytes": n_strings * length,
+            "frac_of_hbm_peak_on_touched_bytes": gbs / HBM_PEAK_GBS, "note": "no early exit: every byte of every string is walked",
             "results_exact": ok}
 
 
-def _timed(img, flat, off, res, device, reps=3):
-    ms = []
-    for _ in range(reps + 1):
-        img.match_tensors(flat, off, res)
-        ms.append(img.last_kernel_ms(device.index or 0))
-    torch.cuda.synchronize()
-    return float(np.mean(ms[1:]))
-
-
-def secondary_config3(device, n_strings=1 << 17, length=65536):
+def secondary_config3(device, capi, n_strings=1 << 17, length=65536):
     """BASELINE.json configs[2] (roofline variant of SURVEY section 8d): example 1, strings of exactly 64 KiB, mix by
     j mod 4: a^(L-1) b, a^L, a^L with one byte at a seeded position set to b, i.i.d. {a: 0.99, b: 0.01}."""
-    img = capi.Image(load_blob("ex1_plain"))
+    import torch
+    blob = load_blob("ex1_plain")
+    img = capi.Image(blob)
     g = torch.Generator(device=device); g.manual_seed(0x5EED0003)
     data = torch.full((n_strings, length), ord("a"), dtype=torch.uint8, device=device)
     data[0::4, -1] = ord("b")
@@ -148,35 +222,130 @@ def secondary_config3(device, n_strings=1 << 17, length=65536):
         mask = torch.rand((r.numel(), length), generator=g, device=device) < 0.01
         data[r] = torch.where(mask, torch.tensor(ord("b"), dtype=torch.uint8, device=device), data[r])
         del mask
+    short = [bytes(data[k, :3000].cpu().numpy().tobytes()) for k in range(8)]
     flat = torch.cat([data.reshape(-1), torch.zeros(64, dtype=torch.uint8, device=device)])
     del data
     off = torch.arange(0, (n_strings + 1) * length, length, dtype=torch.int64, device=device)
     res = torch.empty(n_strings, dtype=torch.uint8, device=device)
-    t = _timed(img, flat, off, res, device)
-    gbs = n_strings * length / (t * 1e-3) / 1e9
+    t, tr = _timed(img, flat, off, res, device)
+    nbytes = n_strings * length
     # a^L is accepted (SURVEY section 8c anchors: aa, aaa, aaaa, aaaaaaaa -> 1), every string containing a b is not
     ok = bool(res[1::4].all().item()) and not bool(res[0::4].any().item()) and not bool(res[2::4].any().item())
+    import oracle_lib
+    data_s, off_s = oracle_lib.pack(short)
+    import numpy as np
+    d_b = torch.zeros(len(data_s) + 64, dtype=torch.uint8, device=device); d_b[:len(data_s)] = torch.from_numpy(data_s.copy())
+    got = img.match_tensors(d_b, torch.from_numpy(off_s.astype(np.int64)).to(device)).cpu().numpy()
     return {"workload": "configs[2]: ({a*}:1&1)*, %d strings of exactly %d bytes, 4-way attack mix" % (n_strings, length),
-            "kernel": "mfa_jit_kernel", "kernel_ms": t, "GB/s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "results_as_expected": ok}
+            "kernel": "region_scan_kernel + mfa_jit_kernel", "region_ms": tr, "walk_ms": t, "GB/s": nbytes / ((t + tr) * 1e-3) / 1e9,
+            # the walk stops at the first empty state set (mfa.cpp:224-225), but the region pass has read every byte by then
+            "touched_bytes": nbytes, "touched_by": "region_scan_kernel reads every byte of every string; the walk reads only the bytes of the steps it executes",
+            "frac_of_hbm_peak_on_touched_bytes": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "region_pass_GB/s": nbytes / (tr * 1e-3) / 1e9 if tr > 0 else None,
+            "results_as_expected": ok, "parity_oracle_sample": _oracle_sample(blob, short, got)}
 
 
-def secondary_config5(device, n_strings=125000):
+def secondary_64k_all_examples(device, capi, corpus, n_strings=16384):
+    """north_star: "at 64 KiB strings" -- all ten examples, every string pumped to 64 KiB (pump size 65536), alternating
+    with / without suffix; per example region pass + walk, back to back."""
+    import numpy as np
+    import torch
+    out = {"workload": "north_star size: 10 examples, %d strings each, pump size exactly 65536, alternating with/without suffix" % n_strings,
+           "kernel": "region_scan_kernel + mfa_jit_kernel, per example, back to back on one stream", "per_example": {}}
+    tot_b, tot_ms = 0, 0.0
+    for ex in sorted(corpus.EXAMPLES):
+        img = capi.Image(load_blob("ex%d_plain" % ex))
+        sizes = np.full(n_strings, 65536, dtype=np.int64)
+        flat, off = corpus.device_batch(ex, sizes, (np.arange(n_strings) % 2) == 0, device)
+        res = torch.empty(n_strings, dtype=torch.uint8, device=device)
+        t, tr = _timed(img, flat, off, res, device, reps=2)
+        nb = int(off[-1].item())
+        out["per_example"][str(ex)] = {"bytes": nb, "region_ms": tr, "walk_ms": t, "GB/s": nb / ((t + tr) * 1e-3) / 1e9, "accepted": int(res.sum().item())}
+        tot_b += nb; tot_ms += t + tr
+        del flat, off, res
+    out["GB/s"] = tot_b / (tot_ms * 1e-3) / 1e9
+    out["touched_bytes"] = tot_b
+    out["frac_of_hbm_peak_on_touched_bytes"] = out["GB/s"] / HBM_PEAK_GBS
+    return out
+
+
+def secondary_no_regions(device, capi, corpus, n_strings=20000, length=4096):
+    """The per-character step rate as a tracked number: in-language text WITHOUT long periodic regions (nothing for the
+    acceleration to skip): example 1's language is every a^n, so a non-periodic in-language text does not exist for it; examples
+    6 and 9 accept texts with irregular block lengths.  Also example 1 on its attack strings with MFA_ACCEL=0 semantics (no
+    region table: every step executed)."""
+    import numpy as np
+    import torch
+    import oracle_lib
+    rng = np.random.default_rng(0x5EED0007)
+    lines = []
+    # ex 6 ({a*}:1b|&1)*: blocks a^k b with the same k repeated are in the language; irregular k keeps regions short
+    # ex 9 (({aa*b}:1(&1)*)|b(b|a*)*)*: b (b|a*)* accepts every string over {a, b} that starts with b
+    gens = {6: lambda: b"".join((b"a" * int(k) + b"b") for k in rng.integers(1, 24, size=length // 12))[:length],
+            9: lambda: b"b" + bytes(rng.choice(list(b"ab"), size=length - 1).tolist())}
+    for ex, gen in gens.items():
+        blob = load_blob("ex%d_plain" % ex)
+        img = capi.Image(blob)
+        base = [gen() for _ in range(64)]
+        strings = [base[k % 64] for k in range(n_strings)]
+        data, off = oracle_lib.pack(strings)
+        d_b = torch.zeros(len(data) + 64, dtype=torch.uint8, device=device); d_b[:len(data)] = torch.from_numpy(data.copy())
+        d_o = torch.from_numpy(off.astype(np.int64)).to(device)
+        res = torch.empty(n_strings, dtype=torch.uint8, device=device)
+        t, tr = _timed(img, d_b, d_o, res, device, reps=2)
+        nb = int(off[-1])
+        short = [s[:1500] for s in base[:8]]
+        ds, os_ = oracle_lib.pack(short)
+        d_s = torch.zeros(len(ds) + 64, dtype=torch.uint8, device=device); d_s[:len(ds)] = torch.from_numpy(ds.copy())
+        got = img.match_tensors(d_s, torch.from_numpy(os_.astype(np.int64)).to(device)).cpu().numpy()
+        lines.append({"workload": "non-periodic text, example %d, %d strings of %d bytes (64 distinct)" % (ex, n_strings, length),
+                      "kernel": "region_scan_kernel + mfa_jit_kernel", "region_ms": tr, "walk_ms": t, "GB/s": nb / ((t + tr) * 1e-3) / 1e9,
+                      "char_steps_per_s": nb / ((t + tr) * 1e-3), "accepted": int(res.sum().item()),
+                      "parity_oracle_sample": _oracle_sample(blob, short, got)})
+        del d_b, d_o, res
+    # example 1, attack strings, no table: every step is executed
+    img = capi.Image(load_blob("ex1_plain"))
+    n1 = 8192
+    sizes = np.full(n1, 4096, dtype=np.int64)
+    flat, off = corpus.device_batch(1, sizes, (np.arange(n1) % 2) == 0, device)
+    res = torch.empty(n1, dtype=torch.uint8, device=device)
+    ms = []
+    for _ in range(3):
+        img.match_tensors_regions(flat, off, None, res)
+        ms.append(img.last_kernel_ms(device.index or 0))
+    nb = int(off[-1].item())
+    t = float(np.mean(ms[1:]))
+    lines.append({"workload": "example 1, %d attack strings of 4 KiB, NO region table (every step executed)" % n1, "kernel": "mfa_jit_kernel",
+                  "walk_ms": t, "GB/s": nb / (t * 1e-3) / 1e9, "char_steps_per_s": nb / (t * 1e-3), "accepted": int(res.sum().item())})
+    return lines
+
+
+def secondary_config5(device, capi, corpus, n_strings=125000):
     """BASELINE.json configs[4]: reversed MFAs (`-reverse`, is_reversed = 1) of the nondeterministic examples 3, 6, 8 on
-    pump-only strings (full walk) and pump+suffix strings (early exit), reported separately.  Images are the reference's
-    own `-reverse` automata (tests/golden/images): this build's front-end has no BNF rewriter yet."""
+    pump-only strings (full walk) and pump+suffix strings (early exit), reported separately."""
+    import numpy as np
+    import torch
     out = []
     for ex in (3, 6, 8):
-        img = capi.Image(load_blob("ex%d_reverse" % ex))
-        n = n_strings if ex != 8 else n_strings // 5             # ex. 8 -reverse has 77 nodes: slot sets in LDS, 16 strings per wave
+        blob = load_blob("ex%d_reverse" % ex)
+        img = capi.Image(blob)
+        n = n_strings if ex != 8 else n_strings // 5
         for tag, suffix in (("pump only", False), ("pump + suffix", True)):
             sizes = corpus.pump_sizes(n, 0x5EED0005 + ex, 1024, 65536)
-            flat, off = corpus.device_batch(ex, sizes, np.full(n, suffix), device)
+            ws = np.full(n, suffix)
+            flat, off = corpus.device_batch(ex, sizes, ws, device)
             res = torch.empty(n, dtype=torch.uint8, device=device)
-            t = _timed(img, flat, off, res, device, reps=2)
+            t, tr = _timed(img, flat, off, res, device, reps=2)
             nbytes = int(off[-1].item())
+            short = [k for k in range(n) if sizes[k] <= 2500][:24]
+            strings = corpus.host_strings(ex, sizes[short], ws[short])
             out.append({"workload": "configs[4]: example %d -reverse, %d strings, %s" % (ex, n, tag),
-                        "kernel": {capi.KERNEL_GENERIC: "mfa_walk_kernel", capi.KERNEL_SPECIALISED: "mfa_jit_kernel"}[img.info()["last_kernel"]],
-                        "kernel_ms": t, "GB/s": nbytes / (t * 1e-3) / 1e9, "accepted": int(res.sum().item())})
+                        "kernel": {capi.KERNEL_GENERIC: "mfa_walk_kernel", capi.KERNEL_SPECIALISED: "region_scan_kernel + mfa_jit_kernel"}[img.info()["last_kernel"]],
+                        "region_ms": tr, "walk_ms": t, "GB/s": nbytes / ((t + tr) * 1e-3) / 1e9,
+                        "touched_bytes": nbytes, "touched_by": "region pass reads every byte; the walk may exit early",
+                        "frac_of_hbm_peak_on_touched_bytes": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "accepted": int(res.sum().item()),
+                        "parity_oracle_sample": _oracle_sample(blob, strings, res[short].cpu().numpy())})
             del flat, off, res
     return out
 
@@ -192,17 +361,29 @@ def main():
     ap.add_argument("--max-len", type=int, default=65536)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="HIP streams the ten launches of a step are spread over (longest-processing-time-first); 0 = try 3, 4 and 6 "
-                         "during set-up and keep the fastest; "
-                         "the runtime maps streams onto four hardware queues, more streams gain nothing")
-    ap.add_argument("--sequential", dest="concurrent", action="store_false",
-                    help="launch the ten examples one after another on one stream instead of on ten streams")
+    ap.add_argument("--walk-streams", type=int, default=3, help="HIP streams the ten walk launches of a step are spread over")
+    ap.add_argument("--region-launches", choices=["per-example", "one"], default="per-example",
+                    help="region pre-pass: one launch per example (walks start as soon as their example is scanned) or one over the whole batch")
+    ap.add_argument("--walk-waves", type=int, default=0, help="development: cap the walk kernels at this many waves per CU (MFA_WALK_WAVES_PER_CU)")
+    ap.add_argument("--exp", default="", help="development: 'region-only' skips the walk launches")
+    ap.add_argument("--order", default="", help="comma-separated example order of a step (default: costliest walk first, measured in set-up)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+
+    import numpy as np
+    import torch
+    from mfa_amd import capi, corpus, sharding
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    if args.walk_waves > 0:
+        os.environ["MFA_WALK_WAVES_PER_CU"] = str(args.walk_waves)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: using WORLD_SIZE\n" % (args.gpus, world))
     # MFA_BENCH_REHEARSE=1: N ranks on ONE GPU with the gloo backend (bitmaps gathered through host memory) -- only to
     # exercise the N > 1 code path on a single-GPU box; real runs use one GPU per rank and RCCL
     rehearse = os.environ.get("MFA_BENCH_REHEARSE") == "1"
@@ -218,100 +399,113 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    comm_dev = torch.device("cpu") if rehearse else device
 
-    # ---- this rank's shard, resident in HBM ---------------------------------------------------------
+    # ---- this rank's shard: ONE mixed batch, resident in HBM ------------------------------------------
     shards = {}
     n_per = args.strings_per_example
-    total_bytes, total_strings = 0, 0
+    parts_b, parts_o, pos_s, pos_b = [], [], 0, 0
     for ex in sorted(corpus.EXAMPLES):
         seed = 0x5EED0004 + 1000 * rank + ex
         sizes = corpus.pump_sizes(n_per, seed, args.min_len, args.max_len)
         with_suffix = (np.arange(n_per) % 2) == 0
         d_bytes, d_off = corpus.device_batch(ex, sizes, with_suffix, device)
+        nbytes = int(d_off[-1].item())
         blob = load_blob("ex%d_plain" % ex)
         img = capi.Image(blob)
         img.prepare(local)
-        nbytes = int(d_off[-1].item())
-        shards[ex] = {"img": img, "bytes": d_bytes, "off": d_off, "n": n_per, "nbytes": nbytes, "blob": blob,
+        parts_b.append(d_bytes[:nbytes])
+        parts_o.append(d_off[:-1] + pos_b)
+        shards[ex] = {"img": img, "n": n_per, "nbytes": nbytes, "blob": blob, "first": pos_s,
                       "sample": corpus.host_strings(ex, sizes[:PARITY_N], with_suffix[:PARITY_N]) if rank == 0 else []}
-        total_bytes += nbytes
-        total_strings += n_per
+        pos_s += n_per
+        pos_b += nbytes
+        del d_bytes, d_off
+    total_strings, total_bytes = pos_s, pos_b
+    bytes_all = torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=device)])
+    off_all = torch.cat(parts_o + [torch.tensor([total_bytes], dtype=torch.int64, device=device)])
+    del parts_b, parts_o
+    torch.cuda.empty_cache()
+    table = torch.empty((total_strings, capi.REGION_WORDS), dtype=torch.int64, device=device)
     results = torch.zeros(total_strings, dtype=torch.uint8, device=device)
-    n_bitmap = (total_strings + 7) // 8
-    comm_dev = torch.device("cpu") if rehearse else device
-    gathered = [torch.empty(n_bitmap, dtype=torch.uint8, device=comm_dev) for _ in range(world)] if (dist and rank == 0) else None
-    kernel_ms = {ex: [] for ex in shards}
-    span_ms = []
-    # one HIP stream per example: the ten launches of a step are independent, so they run concurrently and
-    # the chip is not left idle while one example's longest strings finish
-    main = torch.cuda.current_stream(device)
+
+    main_s = torch.cuda.current_stream(device)
+    region_s = torch.cuda.Stream(device)
+    walk_pool = [torch.cuda.Stream(device) for _ in range(max(1, args.walk_streams))]
     ev_fork = torch.cuda.Event(enable_timing=True)
     ev_join = torch.cuda.Event(enable_timing=True)
+    ev_r0 = {ex: torch.cuda.Event(enable_timing=True) for ex in shards}
+    ev_r1 = {ex: torch.cuda.Event(enable_timing=True) for ex in shards}
     ev_done = {ex: torch.cuda.Event() for ex in shards}
-    res_pos, pos = {}, 0
-    for ex, sh in shards.items():
-        res_pos[ex] = pos
-        pos += sh["n"]
-    # batching policy (setup, untimed): one back-to-back pass measures each example's kernel time; the launches of a
-    # step are then spread over --streams HIP streams longest-first, each onto the least loaded stream, so that the
-    # long examples start at once and no stream is left with a long kernel at the end of the step
-    order = list(shards)
-    streams = {ex: main for ex in shards}
+    ev_rall0, ev_rall1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
-    def launch_all(order_, streams_):
-        ev_fork.record(main)
-        for ex in order_:
-            sh, st = shards[ex], streams_[ex]
-            if st is not main:
-                st.wait_event(ev_fork)
-            sh["img"].match_tensors(sh["bytes"], sh["off"], results[res_pos[ex]:res_pos[ex] + sh["n"]], stream=st)
-            if st is not main:
-                ev_done[ex].record(st)
-                main.wait_event(ev_done[ex])
-        ev_join.record(main)
+    def seg(ex):
+        a = shards[ex]["first"]
+        return a, a + shards[ex]["n"]
 
-    n_streams = 1
-    if args.concurrent and args.streams != 1:
-        launch_all(order, streams)                       # back to back on one stream: each example's own kernel time
-        torch.cuda.synchronize()
-        cost = {ex: shards[ex]["img"].last_kernel_ms(local) for ex in shards}
-        pool = [torch.cuda.Stream(device) for _ in range(min(max(args.streams, 6), len(shards)))]
+    def launch_all(order, where):
+        """one pass over the mixed batch: region pre-pass per example on the region stream, each example's walk on its stream
+        as soon as its regions are known"""
+        ev_fork.record(main_s)
+        region_s.wait_event(ev_fork)
+        if args.region_launches == "one":
+            ev_rall0.record(region_s)
+            capi.region_scan(bytes_all, off_all, table, stream=region_s)
+            ev_rall1.record(region_s)
+        for ex in order:
+            a, b = seg(ex)
+            if args.region_launches != "one":
+                ev_r0[ex].record(region_s)
+                capi.region_scan(bytes_all, off_all[a:b + 1], table[a:b], stream=region_s)
+            ev_r1[ex].record(region_s)
+            st = where[ex]
+            st.wait_event(ev_r1[ex])
+            if args.exp != "region-only" or not walked[0]:
+                shards[ex]["img"].match_tensors_regions(bytes_all, off_all[a:b + 1], table[a:b], results[a:b], stream=st)
+            ev_done[ex].record(st)
+        for ex in order:
+            main_s.wait_event(ev_done[ex])
+        ev_join.record(main_s)
 
-        def schedule(n):
-            load, queue, where = [0.0] * n, [[] for _ in range(n)], {}
-            for ex in sorted(shards, key=lambda e: -cost[e]):
-                k = load.index(min(load))
-                load[k] += cost[ex]
-                queue[k].append(ex)
-                where[ex] = pool[k]
-            return [q[j] for j in range(max(len(q) for q in queue)) for q in queue if j < len(q)], where
+    # set-up (untimed): one pass with every walk on one stream measures each example's walk time; a step then starts the
+    # costliest walks first (their regions are scanned first) and leaves the cheapest one for the end, where it runs alone
+    order = sorted(shards)
+    where = {ex: walk_pool[0] for ex in shards}
+    walked = [False]
+    launch_all(order, where)
+    torch.cuda.synchronize()
+    walked[0] = True
+    cost = {ex: shards[ex]["img"].last_kernel_ms(local) for ex in shards}
+    if args.order:
+        order = [int(x) for x in args.order.split(",")]
+    else:
+        order = sorted(shards, key=lambda e: -cost[e])
+    load = [0.0] * len(walk_pool)
+    for ex in order:
+        k = load.index(min(load))
+        load[k] += cost[ex]
+        where[ex] = walk_pool[k]
 
-        # --streams 0: the stream count is tried out (how well kernels overlap depends on which ones meet): two
-        # untimed passes per candidate, the fastest fork-to-join span wins
-        best = None
-        for n in ([args.streams] if args.streams > 1 else [3, 4, 6]):
-            cand = schedule(min(n, len(shards)))
-            spans = []
-            for _ in range(2 if args.streams < 1 else 0):
-                launch_all(*cand)
-                ev_join.synchronize()
-                spans.append(ev_fork.elapsed_time(ev_join))
-            t = min(spans) if spans else 0.0
-            if best is None or t < best[0]:
-                best = (t, n, cand)
-        n_streams, (order, streams) = best[1], best[2]
+    kernel_ms = {ex: [] for ex in shards}
+    region_ms = {ex: [] for ex in shards}
+    span_ms, region_all_ms = [], []
+    counts = [total_strings] * world
 
     def step(record):
-        launch_all(order, streams)
-        bitmap = sharding.pack_bitmap(results)
-        if dist:
-            dist.gather(bitmap.to(comm_dev), gathered, dst=0)      # RCCL over xGMI: the path's only exchange
+        launch_all(order, where)
+        full = sharding.gather_results(results, counts, dist, rank, world, comm_device=comm_dev) if dist else None
+        if dist is None:
+            full = sharding.pack_bitmap(results)                 # the bitmap a gather would send
         if record:
-            for ex, sh in shards.items():
-                kernel_ms[ex].append(sh["img"].last_kernel_ms(local))
             ev_join.synchronize()
             span_ms.append(ev_fork.elapsed_time(ev_join))
-        return bitmap
+            for ex, sh in shards.items():
+                kernel_ms[ex].append(sh["img"].last_kernel_ms(local))
+                if args.region_launches != "one":
+                    region_ms[ex].append(ev_r0[ex].elapsed_time(ev_r1[ex]))
+            if args.region_launches == "one":
+                region_all_ms.append(ev_rall0.elapsed_time(ev_rall1))
+        return full
 
     def fence():
         torch.cuda.synchronize()
@@ -324,41 +518,45 @@ def main():
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        gathered = step(True)
     fence()
     dt = time.perf_counter() - t0
+    bytes_by_rank = [total_bytes]
     if dist:
         t = torch.tensor([dt], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        bl = [torch.zeros(1, dtype=torch.int64, device=comm_dev) for _ in range(world)]
+        dist.all_gather(bl, torch.tensor([total_bytes], dtype=torch.int64, device=comm_dev))
+        bytes_by_rank = [int(b.item()) for b in bl]
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
-        value = total_bytes * world * args.steps / dt / 1e9
-        # roofline of the dominant kernel (mfa_walk_kernel): algorithmic bytes of one step's launches
-        # (1 B per input character + 8 B offset + 1 B result per string) over their summed durations
+        job_bytes = sum(bytes_by_rank)
+        value = job_bytes * args.steps / dt / 1e9
+        if dist:                                              # rank 0 holds every rank's answers, in rank order
+            assert gathered is not None and gathered.numel() == total_strings * world
+            assert torch.equal(gathered[:total_strings].to(results.device), (results == 1).to(torch.uint8))
+        # roofline: algorithmic bytes of a step (1 B per input character + 8 B offset + 1 B result per string) over the device time
+        # of the step's kernels = the span from the fork event (before the first region launch) to the join event (after the last
+        # walk), HIP events on the streams the kernels run on
         alg = total_bytes + 9 * total_strings
-        # the ten launches overlap: the device time of a step's match work is the span from the fork event
-        # (recorded before the first launch) to the join event (after the last kernel), both HIP events on
-        # the streams the kernels run on
         kern_s = float(np.mean(span_ms)) * 1e-3
         achieved = alg / kern_s / 1e9
-        kinds = {capi.KERNEL_GENERIC: "mfa_walk_kernel", capi.KERNEL_SPECIALISED: "mfa_jit_kernel"}
-        per_ex = {str(ex): {"kernel_ms": float(np.mean(kernel_ms[ex])), "bytes": shards[ex]["nbytes"],
-                            "GB/s": shards[ex]["nbytes"] / (float(np.mean(kernel_ms[ex])) * 1e-3) / 1e9,
-                            "accepted": None} for ex in shards}
-        pos = 0
+        reg_total_ms = float(np.mean(region_all_ms)) if region_all_ms else float(sum(np.mean(region_ms[ex]) for ex in shards))
+        walk_total_ms = float(sum(np.mean(kernel_ms[ex]) for ex in shards))
+        per_ex = {}
         for ex, sh in shards.items():
-            per_ex[str(ex)]["accepted"] = int(results[pos:pos + sh["n"]].sum().item())
-            pos += sh["n"]
-        # HBM traffic of one step from the PMC passes kept under profiles/ (collected separately: counters cannot be
-        # read from inside the run); only quoted when this run is the workload they were collected on
+            a, b = seg(ex)
+            per_ex[str(ex)] = {"bytes": sh["nbytes"], "walk_ms": float(np.mean(kernel_ms[ex])),
+                               "region_ms": float(np.mean(region_ms[ex])) if region_ms[ex] else None,
+                               "accepted": int((results[a:b] == 1).sum().item())}
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01k_traffic.json")) as f:
+            with open(TRAFFIC_FILE) as f:
                 tj = json.load(f)
             wl = tj["workload"]
-            if (wl["strings_per_example"], wl["min_len"], wl["max_len"]) == (n_per, args.min_len, args.max_len) and args.concurrent:
+            if (wl["strings_per_example"], wl["min_len"], wl["max_len"]) == (n_per, args.min_len, args.max_len):
                 traffic = tj["hbm_bytes_per_step"]
         except (OSError, KeyError, ValueError):
             pass
@@ -367,34 +565,45 @@ def main():
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "10 README MFA examples (plain mode), %d pumped attack strings per example per GPU, "
+            "ranks_seen": dist.get_world_size() if dist else 1, "backend": (dist.get_backend() if dist else None),
+            "bytes_by_rank": bytes_by_rank,
+            "config": {"workload": "10 README MFA examples (plain mode) as ONE mixed batch, %d pumped attack strings per example per GPU, "
                                    "pump size log-uniform [%d, %d], alternating with/without suffix "
                                    "(BASELINE configs[3] shard: 10M strings over 8 GPUs)" % (n_per, args.min_len, args.max_len),
-                       "strings_per_example": n_per, "min_len": args.min_len, "max_len": args.max_len, "strings_per_gpu": total_strings, "bytes_per_gpu": total_bytes, "parallelism": "dp%d" % world,
-                       "exchange": "gather of the result bitmap to rank 0" + (" (RCCL)" if dist else " (single rank: none)")},
+                       "strings_per_example": n_per, "min_len": args.min_len, "max_len": args.max_len, "strings_per_gpu": total_strings,
+                       "bytes_per_gpu": total_bytes, "parallelism": "dp%d" % world,
+                       "exchange": "gather of the result bitmap to rank 0" + (" (%s)" % dist.get_backend() if dist else " (single rank: none)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "%s: 10 launches per step, one per example, %s" % (
-                             "/".join(sorted({kinds[sh["img"].info()["last_kernel"]] for sh in shards.values()})),
-                             "concurrent on %d streams, longest first (duration = fork-to-join span)" % n_streams if args.concurrent else "back to back on one stream"),
-                         "algorithmic_bytes_per_step": alg,
-                         # mean duration of one of the step's dispatches (own start/stop events; they overlap): what a kernel trace's
-                         # per-dispatch durations of the timed steps average to (profiles/*_span_check.txt lists their sum per step)
-                         "dispatch_ms_mean": float(np.mean([np.mean(kernel_ms[ex]) for ex in shards])), "kernel_seconds_per_step": kern_s},
-            "per_example": per_ex,
+                         "kernel": "region_scan_kernel (%s) + mfa_jit_kernel (10 launches on %d streams, costliest first); duration = fork-to-join span of a step" % (
+                             "1 launch" if args.region_launches == "one" else "10 launches, one per example, on one stream", len(walk_pool)),
+                         "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s,
+                         # the kernel that reads the bytes: its own launches, timed with HIP events on its stream
+                         "region_scan_kernel": {"launches_per_step": 1 if region_all_ms else len(shards), "ms_per_step": reg_total_ms,
+                                                "ms_per_launch": reg_total_ms / (1 if region_all_ms else len(shards)),
+                                                "achieved": total_bytes / (reg_total_ms * 1e-3) / 1e9, "frac": total_bytes / (reg_total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                "note": "runs beside the walk kernels of earlier examples"},
+                         "mfa_jit_kernel": {"launches_per_step": len(shards), "ms_sum_per_step": walk_total_ms,
+                                            "dispatch_ms_mean": walk_total_ms / len(shards)}},
+            "order": order, "per_example": per_ex,
         }
         if not args.no_cpu_baseline and world == 1:
-            pos, gpu_res = 0, {}
-            for ex, sh in shards.items():
-                gpu_res[ex] = results[pos:pos + PARITY_N].cpu().numpy()
-                pos += sh["n"]
-            out["cpu_baseline"] = cpu_baseline(shards, gpu_res)
+            gpu_res = {ex: results[sh["first"]:sh["first"] + PARITY_N].cpu().numpy() for ex, sh in shards.items()}
+            out["cpu_baseline"] = cpu_baseline(corpus, shards, gpu_res)
         if not args.no_secondary and world == 1:
-            for sh in shards.values():                   # free the headline shard before the other configurations
-                sh["bytes"] = sh["off"] = None
+            del bytes_all, off_all, table
             torch.cuda.empty_cache()
-            out["secondary"] = [secondary_dfa(device), secondary_config3(device)] + secondary_config5(device)
+            sec = [secondary_dfa(device, capi), secondary_config3(device, capi), secondary_64k_all_examples(device, capi, corpus)]
+            sec += secondary_no_regions(device, capi, corpus)
+            sec += secondary_config5(device, capi, corpus)
+            out["secondary"] = sec
         print(json.dumps(out))
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_last.json"), "w") as f:
+                f.write(json.dumps(out) + "\n")
+        except OSError:
+            pass
     if dist:
         dist.barrier()
         dist.destroy_process_group()

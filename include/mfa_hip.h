@@ -14,9 +14,10 @@
  *
  * Plain C types only: pointers and sizes.  No exceptions cross this boundary;
  * every function returns 0 (MFA_OK) or a negative MFA_ERR_* code.  The caller owns
- * every buffer it passes.  Functions are re-entrant per (image, device, stream);
- * one image may be used from several host threads as long as they use different
- * streams or serialise their calls.
+ * every buffer it passes.  Functions are re-entrant per (image, device, stream):
+ * every launch takes its own workspace (ticket counter, scratch, region table,
+ * events) from a per-image pool, so one image may be used from several host threads
+ * and on several streams at the same time; launches on one stream run in stream order.
  *
  * There is NO CPU fallback: without a usable HIP device the match entry points
  * return MFA_ERR_NO_DEVICE.
@@ -99,6 +100,31 @@ int  mfa_image_specialize(mfa_image_t* img);
 int  mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                      uint8_t* d_results, int device, void* stream);
 
+/* ---- region tables -------------------------------------------------------------------------------
+ * Before a memory automaton walks a batch, one streaming pass over the batch (region_scan_kernel)
+ * finds every string's periodic regions -- stretches with s[j] == s[j+q], q <= 8 -- and leaves them in
+ * a table the walk kernels look up instead of measuring the stretches themselves.  mfa_match_batch
+ * runs that pass itself; it is exported for callers that match SEVERAL automata against the same
+ * batch (mfa_match_batch_regions: the pass then runs once) and for tests.
+ * Table layout: MFA_REGION_WORDS uint64 per string; word 0 = count | flags, then `count` entries
+ *   lo | hi << 24 | q << 48     (offsets relative to the start of the string, memory order)
+ * Every entry is true (s[j] == s[j+q] for lo <= j < hi - q) and entries with q = 1 are maximal runs.
+ * MFA_REGION_OVERFLOW in word 0: the string has more regions than fit and the table holds the longest
+ * (or the string is too long to be matched): the walk then executes the other stretches step by step. */
+#define MFA_REGION_WORDS    16u
+#define MFA_REGION_MAX      15u
+#define MFA_REGION_OVERFLOW 0x100ull
+#define MFA_REGION_MIN_LEN  64u
+
+/* d_table: device buffer of n * MFA_REGION_WORDS uint64.  Asynchronous on `stream`. */
+int  mfa_region_scan(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table,
+                     int device, void* stream);
+
+/* mfa_match_batch with a region table the caller has already filled for this batch on this stream
+ * (or on a stream this one waits for).  d_table == NULL: no table, every step is executed. */
+int  mfa_match_batch_regions(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                             uint8_t* d_results, const uint64_t* d_table, int device, void* stream);
+
 /* Same with HOST pointers: copies the batch to the device, matches, copies the
  * results back, synchronises.  Convenience for callers that hold std::strings
  * (the CLI); throughput is then bounded by the host link, not by the kernel. */
@@ -109,6 +135,8 @@ int  mfa_match_batch_host(mfa_image_t* img, const uint8_t* bytes, const uint64_t
  * `device`, in milliseconds, measured with HIP events recorded on the launch stream
  * around the kernel alone.  Synchronises on the stop event. */
 int  mfa_last_kernel_ms(mfa_image_t* img, int device, float* ms);
+/* Device-side time of the region pass of that launch (0 if it ran none). */
+int  mfa_last_region_ms(mfa_image_t* img, int device, float* ms);
 
 int         mfa_device_count(void);        /* >= 0, or MFA_ERR_NO_DEVICE */
 int         mfa_last_hip_error(void);      /* hipError_t of the last failed HIP call on this thread */

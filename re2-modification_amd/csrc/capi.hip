@@ -18,6 +18,59 @@ void set_last_hip_error(int e) { g_last_hip_error = e; }
         if (e_ != hipSuccess) { set_last_hip_error((int)e_); return MFA_ERR_HIP; } \
     } while (0)
 
+static void ctx_free(LaunchCtx& cx) {
+    if (cx.d_counter) (void)hipFree(cx.d_counter);
+    if (cx.d_scratch) (void)hipFree(cx.d_scratch);
+    if (cx.d_regions) (void)hipFree(cx.d_regions);
+    for (void* ev : {cx.ev_start, cx.ev_stop, cx.ev_r0, cx.ev_r1, cx.ev_done})
+        if (ev) (void)hipEventDestroy((hipEvent_t)ev);
+    cx = LaunchCtx{};
+}
+
+// grow *buf to `need` bytes (contents are not kept).  Frees the old buffer first: hipFree waits for the device, so a
+// kernel of an earlier launch on the same stream that still uses it has finished by then.
+int ctx_reserve(void** buf, size_t* have, size_t need) {
+    if (need <= *have) return MFA_OK;
+    if (*buf) HIP_TRY(hipFree(*buf));
+    *buf = nullptr; *have = 0;
+    need += need / 4;                                         // head room: batches of similar size do not reallocate
+    HIP_TRY(hipMalloc(buf, need));
+    *have = need;
+    return MFA_OK;
+}
+
+// A context for a launch on `stream`: the one this stream used last (its work is ordered before ours), else one whose
+// last launch has completed, else a new one.  The caller holds the image mutex and has set the device.
+int ctx_acquire(DeviceState& ds, void* stream, LaunchCtx** out) {
+    LaunchCtx* pick = nullptr;
+    for (LaunchCtx* cx : ds.ctxs)
+        if (cx->used && cx->stream == stream) { pick = cx; break; }
+    if (!pick)
+        for (LaunchCtx* cx : ds.ctxs)
+            if (!cx->used || hipEventQuery((hipEvent_t)cx->ev_done) == hipSuccess) { pick = cx; break; }
+    if (!pick && ds.ctxs.size() >= 64) {                       // far more overlapping launches than a device runs at once: wait for the oldest
+        pick = ds.ctxs.front();
+        HIP_TRY(hipEventSynchronize((hipEvent_t)pick->ev_done));
+    }
+    if (!pick) {
+        LaunchCtx* cx = new (std::nothrow) LaunchCtx();
+        if (!cx) return MFA_ERR_NOMEM;
+        hipError_t e = hipMalloc((void**)&cx->d_counter, 256 + (getenv("MFA_STATS") ? (4u << 20) : 0));
+        if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&cx->ev_start);
+        if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&cx->ev_stop);
+        if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&cx->ev_r0);
+        if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&cx->ev_r1);
+        if (e == hipSuccess) e = hipEventCreateWithFlags((hipEvent_t*)&cx->ev_done, hipEventDisableTiming);
+        if (e != hipSuccess) { set_last_hip_error((int)e); ctx_free(*cx); delete cx; return MFA_ERR_HIP; }
+        ds.ctxs.push_back(cx);
+        pick = cx;
+    }
+    pick->used = true; pick->stream = stream; pick->ran_regions = false;
+    ds.last = pick;
+    *out = pick;
+    return MFA_OK;
+}
+
 void device_release(DeviceState& ds) {
     if (ds.device < 0) return;
     int cur = -1;
@@ -28,11 +81,8 @@ void device_release(DeviceState& ds) {
     if (ds.d_dfa_trans) (void)hipFree(ds.d_dfa_trans);
     if (ds.d_dfa_accept) (void)hipFree(ds.d_dfa_accept);
     if (ds.d_byte_class) (void)hipFree(ds.d_byte_class);
-    if (ds.d_counter) (void)hipFree(ds.d_counter);
-    if (ds.d_scratch) (void)hipFree(ds.d_scratch);
+    for (LaunchCtx* cx : ds.ctxs) { ctx_free(*cx); delete cx; }
     jit_unload(ds);
-    if (ds.ev_start) (void)hipEventDestroy((hipEvent_t)ds.ev_start);
-    if (ds.ev_stop) (void)hipEventDestroy((hipEvent_t)ds.ev_stop);
     ds = DeviceState{};
     (void)hipSetDevice(cur);
 }
@@ -64,14 +114,7 @@ int device_prepare(mfa_image* img, int device, DeviceState** out) {
         if (rc == MFA_OK) rc = up((void**)&ds.d_dfa_accept, h.dfa_accept.data(), h.dfa_accept.size());
         if (rc == MFA_OK) rc = up((void**)&ds.d_byte_class, h.byte_class, 256);
     }
-    if (rc == MFA_OK) {
-        hipError_t e = hipMalloc((void**)&ds.d_counter, 256 + (getenv("MFA_STATS") ? (4u << 20) : 0));
-        if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&ds.ev_start);
-        if (e == hipSuccess) e = hipEventCreate((hipEvent_t*)&ds.ev_stop);
-        if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }
-    }
     if (rc != MFA_OK) { device_release(ds); return rc; }
-    ds.timed = true;
     auto ins = img->dev.emplace(device, ds);
     *out = &ins.first->second;
     return MFA_OK;
@@ -131,8 +174,15 @@ int mfa_image_specialize(mfa_image_t* img) {
     return MFA_OK;
 }
 
-int mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
-                    int device, void* stream) {
+static bool regions_enabled() {
+    const char* e = getenv("MFA_REGIONS");                      // MFA_REGIONS=0: no region pass, the walk measures regions itself (A/B runs)
+    const char* a = getenv("MFA_ACCEL");
+    return !(e && e[0] == '0') && !(a && a[0] == '0');
+}
+
+// own_regions: run the region pass into the context's table; else use d_table (may be NULL)
+static int match_impl(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
+                      const uint64_t* d_table, bool own_regions, int device, void* stream) {
     if (!img || !d_offsets || (!d_results && n)) return MFA_ERR_INVALID_ARG;
     if (n == 0) return MFA_OK;
     std::lock_guard<std::mutex> lk(img->mu);
@@ -140,16 +190,58 @@ int mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_
     int rc = device_prepare(img, device, &ds);
     if (rc != MFA_OK) return rc;
     HIP_TRY(hipSetDevice(device));
-    if (img->host.h.kind == MFA_KIND_MFA) {
-        if (jit_load(img->host, *ds)) {
-            img->last_kernel = MFA_KERNEL_SPECIALISED;
-            return launch_mfa_jit(*ds, d_bytes, d_offsets, n, d_results, stream);
+    const bool is_mfa = img->host.h.kind == MFA_KIND_MFA;
+    const bool jit = is_mfa && jit_load(img->host, *ds);
+    LaunchCtx* cx = nullptr;
+    rc = ctx_acquire(*ds, stream, &cx);
+    if (rc != MFA_OK) return rc;
+    if (jit) {
+        img->last_kernel = MFA_KERNEL_SPECIALISED;
+        if (own_regions && regions_enabled()) {
+            rc = ctx_reserve((void**)&cx->d_regions, &cx->region_bytes, (size_t)n * MFA_REGION_WORDS * sizeof(uint64_t));
+            if (rc != MFA_OK) return rc;
+            HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_r0, (hipStream_t)stream));
+            rc = launch_region_scan(ds->n_cus, d_bytes, d_offsets, n, cx->d_regions, stream);
+            if (rc != MFA_OK) return rc;
+            HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_r1, (hipStream_t)stream));
+            cx->ran_regions = true;
+            d_table = cx->d_regions;
         }
+        rc = launch_mfa_jit(*ds, *cx, d_bytes, d_offsets, n, d_results, d_table, stream);
+    } else if (is_mfa) {
         img->last_kernel = MFA_KERNEL_GENERIC;
-        return launch_mfa_walk(img->host, *ds, d_bytes, d_offsets, n, d_results, stream);
+        rc = launch_mfa_walk(img->host, *ds, *cx, d_bytes, d_offsets, n, d_results, stream);
+    } else {
+        img->last_kernel = MFA_KERNEL_TABLE;
+        rc = launch_dfa_walk(img->host, *ds, *cx, d_bytes, d_offsets, n, d_results, stream);
     }
-    img->last_kernel = MFA_KERNEL_TABLE;
-    return launch_dfa_walk(img->host, *ds, d_bytes, d_offsets, n, d_results, stream);
+    HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_done, (hipStream_t)stream));
+    return rc;
+}
+
+int mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
+                    int device, void* stream) {
+    return match_impl(img, d_bytes, d_offsets, n, d_results, nullptr, true, device, stream);
+}
+
+int mfa_match_batch_regions(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
+                            const uint64_t* d_table, int device, void* stream) {
+    return match_impl(img, d_bytes, d_offsets, n, d_results, d_table, false, device, stream);
+}
+
+int mfa_region_scan(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, int device, void* stream) {
+    if (!d_offsets || (!d_table && n)) return MFA_ERR_INVALID_ARG;
+    if (n == 0) return MFA_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MFA_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    static int cus[64] = {0};
+    if (device < 64 && cus[device] == 0) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, device));
+        cus[device] = prop.multiProcessorCount;
+    }
+    return launch_region_scan(device < 64 ? cus[device] : 256, d_bytes, d_offsets, n, d_table, stream);
 }
 
 int mfa_match_batch_host(mfa_image_t* img, const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* results,
@@ -199,10 +291,24 @@ int mfa_last_kernel_ms(mfa_image_t* img, int device, float* ms) {
     if (!img || !ms) return MFA_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(img->mu);
     auto it = img->dev.find(device);
-    if (it == img->dev.end() || !it->second.timed) return MFA_ERR_INVALID_ARG;
-    HIP_TRY(hipEventSynchronize((hipEvent_t)it->second.ev_stop));
-    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)it->second.ev_start, (hipEvent_t)it->second.ev_stop));
-    jit_print_stats(it->second, "last kernel");
+    if (it == img->dev.end() || !it->second.last) return MFA_ERR_INVALID_ARG;
+    LaunchCtx& cx = *it->second.last;
+    HIP_TRY(hipEventSynchronize((hipEvent_t)cx.ev_stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)cx.ev_start, (hipEvent_t)cx.ev_stop));
+    jit_print_stats(cx, "last kernel");
+    return MFA_OK;
+}
+
+int mfa_last_region_ms(mfa_image_t* img, int device, float* ms) {
+    if (!img || !ms) return MFA_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(img->mu);
+    auto it = img->dev.find(device);
+    if (it == img->dev.end() || !it->second.last) return MFA_ERR_INVALID_ARG;
+    LaunchCtx& cx = *it->second.last;
+    *ms = 0.0f;
+    if (!cx.ran_regions) return MFA_OK;
+    HIP_TRY(hipEventSynchronize((hipEvent_t)cx.ev_r1));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)cx.ev_r0, (hipEvent_t)cx.ev_r1));
     return MFA_OK;
 }
 

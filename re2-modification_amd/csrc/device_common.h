@@ -38,6 +38,9 @@ struct Input {
     // the periodic region known before that one (a cell captured there may be read inside the current one)
     uint32_t prev_lo, prev_hi, prev_q;
     uint32_t dual_p;        // steps per period of the dual step in flight (slope of i), 0 in plain steps
+    // region table of this string (regions.hip), nullptr = none: the lane measures regions itself
+    const uint64_t* rt;
+    uint32_t rt_cnt;
 };
 
 __device__ __forceinline__ void input_reset(Input& in, uint64_t base, uint32_t len) {
@@ -46,6 +49,58 @@ __device__ __forceinline__ void input_reset(Input& in, uint64_t base, uint32_t l
     in.run_lo = in.run_hi = 0; in.run_ch = 0x100u;
     in.per_lo = in.per_hi = 0; in.per_q = 0; in.dual_p = 0;
     in.prev_lo = in.prev_hi = 0; in.prev_q = 0;
+    in.rt = nullptr; in.rt_cnt = 0;
+}
+
+// ---- region table (regions.hip; layout in include/mfa_hip.h) -------------------------------------------
+#define MFA_RT_WORDS 16u
+#define MFA_RT_OVERFLOW 0x100ull
+
+// attach the table of string `sid`.  Every entry is a true region; when the string had more regions than fit (overflow flag)
+// the table holds the longest ones, which only means that the lane walks through the others step by step.
+__device__ __forceinline__ void rt_attach(Input& in, const uint64_t* regions, uint64_t sid) {
+    if (regions == nullptr) return;
+    const uint64_t* t = regions + sid * MFA_RT_WORDS;
+    in.rt = t; in.rt_cnt = (uint32_t)t[0] & 0xffu;
+}
+
+// entry e in scan coordinates: scan[j] == scan[j + q] for lo <= j < hi - q
+template <bool REV>
+__device__ __forceinline__ void rt_entry(const Input& in, uint32_t e, uint32_t& lo, uint32_t& hi, uint32_t& q) {
+    const uint64_t w = in.rt[1u + e];
+    const uint32_t mlo = (uint32_t)w & 0x00ffffffu, mhi = (uint32_t)(w >> 24) & 0x00ffffffu;
+    q = (uint32_t)(w >> 48) & 15u;
+    lo = REV ? in.len - mhi : mlo;
+    hi = REV ? in.len - mlo : mhi;
+}
+
+// The region with the smallest period that contains scan index i and leaves room for a probe (the caller's rule:
+// hi - i >= 4 q mult + 24).  next = the nearest region start behind i, ~0u if there is none.
+template <bool REV>
+__device__ __forceinline__ bool rt_find(const Input& in, uint32_t i, uint32_t mult, uint32_t& lo, uint32_t& hi, uint32_t& q, uint32_t& next) {
+    bool found = false;
+    next = ~0u;
+    for (uint32_t e = 0; e < in.rt_cnt; e++) {
+        uint32_t l, h, qq;
+        rt_entry<REV>(in, e, l, h, qq);
+        if (l <= i && i < h) {
+            const uint32_t m = qq * mult > 16u ? 1u : mult;
+            if (h - i >= 4u * qq * m + 24u && (!found || qq < q)) { found = true; lo = l; hi = h; q = qq; }
+        } else if (l > i && l < next) next = l;
+    }
+    return found;
+}
+
+// exclusive end of the run of equal bytes that contains scan index i, if the table has it (entries with q = 1 are
+// maximal at both ends); after a miss the caller measures the run (it is short unless the table overflowed)
+template <bool REV>
+__device__ __forceinline__ bool rt_run(const Input& in, uint32_t i, uint32_t& hi) {
+    for (uint32_t e = 0; e < in.rt_cnt; e++) {
+        uint32_t l, h, qq;
+        rt_entry<REV>(in, e, l, h, qq);
+        if (qq == 1u && l <= i && i < h) { hi = h; return true; }
+    }
+    return false;
 }
 
 // scan index j -> byte offset (reversed automata scan the string backwards: mfa.cpp:163-166)
@@ -339,6 +394,57 @@ __device__ __forceinline__ uint32_t coop_period_end_rev(const uint8_t* bytes, ui
     const unsigned long long b = __ballot(bad);
     if (b) return i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b) + q;
     return len;
+}
+
+// Exclusive end (scan index) of the run of equal bytes that starts at scan index i0: the q = 1 case of the scans above with a
+// shallow pipeline (MFA_RUN_DEPTH blocks per lane in flight).  The walk kernels call it for cell reads of one-byte-repeated
+// values whose run the region table does not hold -- runs shorter than MFA_REGION_MIN_LEN, or any run when there is no table.
+#ifndef MFA_RUN_DEPTH
+#define MFA_RUN_DEPTH 2
+#endif
+template <bool REV>
+__device__ __forceinline__ uint32_t coop_run_end(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t lane) {
+    if (i0 + 1u >= len) return len;
+    constexpr int D = MFA_RUN_DEPTH;
+    const uint32_t nblk = (len - 1u - i0) >> 4;          // whole blocks of positions i0 .. len-2 (each compared with the run's byte)
+    if (!REV) {
+        const uint8_t* p = bytes + base;
+        const uint32_t cc = (uint32_t)p[i0] * 0x01010101u;
+        const uint32_t r = run_blocks_fwd<D>(p + i0, nblk, cc, lane);
+        if (r != ~0u) return i0 + r;
+        const uint32_t j = i0 + 16u * nblk + lane;       // fewer than 17 positions left
+        const unsigned long long b1 = __ballot(lane < 17u && j < len && p[j] != (uint8_t)cc);
+        return b1 ? i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b1) : len;
+    }
+    const uint8_t* top = bytes + base + (len - 1u - i0);  // address of scan index i0; the scan runs towards lower addresses
+    const uint32_t cc = (uint32_t)*top * 0x01010101u;
+    for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
+        uint4 x[D];
+#pragma unroll
+        for (int k = 0; k < D; k++) {
+            const uint32_t t = t0 + 64u * k + lane;
+            x[k] = make_uint4(cc, cc, cc, cc);
+            if (t < nblk) __builtin_memcpy(&x[k], top - 16u * t - 15u, 16);      // scan indices i0+16t .. i0+16t+15
+        }
+        bool any_diff = false;
+#pragma unroll
+        for (int k = 0; k < D; k++) any_diff = any_diff || ((x[k].x ^ cc) | (x[k].y ^ cc) | (x[k].z ^ cc) | (x[k].w ^ cc)) != 0u;
+        if (__any(any_diff)) {
+#pragma unroll
+            for (int k = 0; k < D; k++) {
+                const uint32_t m = nz16(make_uint4(x[k].x ^ cc, x[k].y ^ cc, x[k].z ^ cc, x[k].w ^ cc));
+                const unsigned long long b = __ballot(m != 0u);
+                if (b) {
+                    const int L = __builtin_ctzll(b);
+                    const uint32_t mm = __shfl(m, L);      // the highest address is the first scan index: highest set bit
+                    return i0 + 16u * (t0 + 64u * k + (uint32_t)L) + (15u - (31u - (uint32_t)__builtin_clz(mm)));
+                }
+            }
+        }
+    }
+    const uint32_t j = i0 + 16u * nblk + lane;           // fewer than 17 positions left
+    const unsigned long long b1 = __ballot(lane < 17u && j < len && *(bytes + base + (len - 1u - j)) != (uint8_t)cc);
+    return b1 ? i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b1) : len;
 }
 
 template <bool REV>

@@ -3,6 +3,7 @@
 // with hipModuleLaunchKernel.  Everything here is optional: if generation, compilation or loading
 // fails the launcher uses the generic kernel of kernels.hip (still on the GPU).
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <spawn.h>
 #include <sys/stat.h>
@@ -23,7 +24,7 @@ extern char** environ;
 
 namespace mfa {
 
-static const char* kGeneratorVersion = "jit-60";
+static const char* kCompileFlags[] = {"--genco", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Rpass-analysis=kernel-resource-usage"};
 
 static std::string cache_dir() {
     if (const char* e = getenv("MFA_JIT_CACHE")) return e;
@@ -33,7 +34,9 @@ static std::string cache_dir() {
         size_t slash = p.rfind('/');
         return (slash == std::string::npos ? std::string(".") : p.substr(0, slash)) + "/jit_cache";
     }
-    return "/tmp/mfa_jit_cache";
+    char buf[64];
+    snprintf(buf, sizeof buf, "/tmp/mfa_jit_cache_%u", (unsigned)getuid());      // per user, created 0700
+    return buf;
 }
 
 static uint64_t fnv1a(const void* data, size_t n, uint64_t h) {
@@ -47,17 +50,16 @@ static bool stats_build() {
     return e && e[0] != '0' && e[0] != 0;
 }
 
-static std::string image_key(const HostImage& img) {
-    uint64_t h = 1469598103934665603ull;
-    h = fnv1a(kGeneratorVersion, strlen(kGeneratorVersion), h);
-    if (stats_build()) h = fnv1a("stats", 5, h);
-    for (const char* k : {"MFA_GEN_SCAN_DEPTH", "MFA_GEN_LB2_WORDS", "MFA_GEN_LDS_BUDGET", "MFA_GEN_PROBE_PERIODS", "MFA_GEN_LOOK_EVERY"})
-        if (const char* e = getenv(k)) h = fnv1a(e, strlen(e), fnv1a(k, strlen(k), h));
-    h = fnv1a(&img.h, sizeof img.h, h);
-    h = fnv1a(img.edge_begin.data(), img.edge_begin.size() * 4, h);
-    h = fnv1a(img.edges.data(), img.edges.size() * sizeof(mfa_blob_edge), h);
-    char buf[32];
-    snprintf(buf, sizeof buf, "%016llx", (unsigned long long)h);
+// The key covers everything the code object depends on: the generated source itself (which embeds
+// device_common.h, the automaton and the development knobs) and the compile flags.
+static std::string source_key(const std::string& src) {
+    uint64_t h = 1469598103934665603ull, g = 0x9e3779b97f4a7c15ull;
+    h = fnv1a(src.data(), src.size(), h);
+    for (const char* f : kCompileFlags) { h = fnv1a(f, strlen(f), h); g = fnv1a(f, strlen(f), g); }
+    if (stats_build()) { h = fnv1a("stats", 5, h); g = fnv1a("stats", 5, g); }
+    g = fnv1a(src.data(), src.size(), g);
+    char buf[40];
+    snprintf(buf, sizeof buf, "%016llx%08x", (unsigned long long)h, (unsigned)(g >> 32));
     return buf;
 }
 
@@ -75,39 +77,55 @@ static bool file_exists(const std::string& p) {
 // generate + compile into the cache (host-only, no GPU needed); returns the code-object path or ""
 std::string jit_compile(const HostImage& img, std::string* err) {
     if (!jit_enabled(img)) { if (err) *err = "automaton too large for the specialised kernel"; return ""; }
-    const std::string dir = cache_dir(), key = image_key(img);
-    const std::string src = dir + "/" + key + ".hip", obj = dir + "/" + key + ".hsaco";
+    const std::string text = jit_generate_source(img);
+    const std::string dir = cache_dir(), key = source_key(text);
+    const std::string obj = dir + "/" + key + ".hsaco";
     if (file_exists(obj)) return obj;
-    mkdir(dir.c_str(), 0755);
-    {
-        std::ofstream f(src);
-        if (!f.is_open()) { if (err) *err = "cannot write " + src; return ""; }
-        f << jit_generate_source(img);
-    }
-    const char* hipcc = getenv("MFA_HIPCC");
-    std::string cc = hipcc ? hipcc : "/opt/rocm/bin/hipcc";
+    mkdir(dir.c_str(), 0700);
     static std::atomic<unsigned> serial{0};
     char tmpl[64];
     snprintf(tmpl, sizeof tmpl, ".tmp%d_%u", (int)getpid(), serial.fetch_add(1));
-    std::string tmp = obj + tmpl, log = tmp + ".log";
+    // every compiler run works on files of its own (source, object, log) and renames them into place when done:
+    // ranks and threads that meet on a cold cache never read each other's half-written files
+    const std::string src = dir + "/" + key + tmpl + ".hip", tmp = obj + tmpl, log = tmp + ".log";
+    {
+        std::ofstream f(src);
+        if (!f.is_open()) { if (err) *err = "cannot write " + src; return ""; }
+        f << text;
+    }
+    const char* hipcc = getenv("MFA_HIPCC");
+    const std::string cc = hipcc ? hipcc : "/opt/rocm/bin/hipcc";
+    std::vector<std::string> words = {cc};
+    for (const char* f : kCompileFlags) words.push_back(f);
+    if (stats_build()) words.push_back("-DMFA_STATS_BUILD=1");
+    words.push_back("-o"); words.push_back(tmp); words.push_back(src);
+    std::vector<char*> argv;
+    for (auto& w : words) argv.push_back(const_cast<char*>(w.c_str()));
+    argv.push_back(nullptr);
     // the resource-usage remarks (VGPRs, LDS, scratch, occupancy) of a successful build are kept next to the object
-    std::string cmd = cc + " --genco --offload-arch=gfx950 -O3 -std=c++17 -Rpass-analysis=kernel-resource-usage" +
-                      (stats_build() ? " -DMFA_STATS_BUILD=1" : "") + " -o '" + tmp + "' '" + src + "' > '" + log + "' 2>&1";
-    const char* argv[] = {"/bin/sh", "-c", cmd.c_str(), nullptr};
+    posix_spawn_file_actions_t fa;
+    posix_spawn_file_actions_init(&fa);
+    posix_spawn_file_actions_addopen(&fa, 1, log.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    posix_spawn_file_actions_adddup2(&fa, 1, 2);
     pid_t pid;
-    if (posix_spawn(&pid, "/bin/sh", nullptr, nullptr, (char* const*)argv, environ) != 0) {
-        if (err) *err = "cannot start the compiler";
+    const int sp = posix_spawn(&pid, cc.c_str(), &fa, nullptr, argv.data(), environ);
+    posix_spawn_file_actions_destroy(&fa);
+    if (sp != 0) {
+        unlink(src.c_str());
+        if (err) *err = "cannot start the compiler " + cc;
         return "";
     }
     int status = 0;
     if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0 || !file_exists(tmp)) {
         unlink(tmp.c_str());
-        if (file_exists(obj)) { unlink(log.c_str()); return obj; }      // another thread or process got there first
+        if (file_exists(obj)) { unlink(log.c_str()); unlink(src.c_str()); return obj; }      // another thread or process got there first
+        rename(src.c_str(), (dir + "/" + key + ".failed.hip").c_str());
         if (err) *err = "hipcc failed, see " + log;
         return "";
     }
-    rename(tmp.c_str(), obj.c_str());
+    rename(src.c_str(), (dir + "/" + key + ".hip").c_str());
     rename(log.c_str(), (dir + "/" + key + ".log").c_str());
+    rename(tmp.c_str(), obj.c_str());
     return obj;
 }
 
@@ -136,45 +154,43 @@ bool jit_load(const HostImage& img, DeviceState& ds) {
     return true;
 }
 
-int launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
-                   void* stream) {
+int launch_mfa_jit(DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
+                   const uint64_t* d_regions, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(ds.d_counter, 0, sizeof(unsigned long long), s);
+    hipError_t e = hipMemsetAsync(cx.d_counter, 0, sizeof(unsigned long long), s);
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
     uint64_t grid = (uint64_t)ds.n_cus * ds.jit_waves_per_cu, want = (n + ds.jit_lanes - 1) / ds.jit_lanes;
+    if (const char* g = getenv("MFA_WALK_WAVES_PER_CU")) {            // development knob: waves per CU of the walk launch
+        const int w = atoi(g);
+        if (w > 0 && w < ds.jit_waves_per_cu) grid = (uint64_t)ds.n_cus * w;
+    }
     if (grid > want) grid = want;
     if (grid == 0) grid = 1;
     const char* ae = getenv("MFA_ACCEL");
     uint32_t accel = (ae && ae[0] == '0') ? 0u : 1u;                  // MFA_ACCEL=0: execute every step (A/B testing)
     // probe storage: three slot-set images per wave (jit_gen.cpp)
-    const size_t need = (size_t)grid * 3u * ds.jit_words * 64u * sizeof(uint32_t);
-    if (need > ds.scratch_bytes) {
-        if (ds.d_scratch) (void)hipFree(ds.d_scratch);
-        ds.d_scratch = nullptr; ds.scratch_bytes = 0;
-        e = hipMalloc((void**)&ds.d_scratch, need);
-        if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
-        ds.scratch_bytes = need;
-    }
+    int rc = ctx_reserve((void**)&cx.d_scratch, &cx.scratch_bytes, (size_t)grid * 3u * ds.jit_words * 64u * sizeof(uint32_t));
+    if (rc != MFA_OK) return rc;
     // MFA_STATS=1: the kernel adds its iteration / probe counters to 6 words behind the ticket counter
-    unsigned long long* stats = getenv("MFA_STATS") ? ds.d_counter + 1 : nullptr;      // + per-string executed steps at stats+8 (u32, first 1M strings)
+    unsigned long long* stats = getenv("MFA_STATS") ? cx.d_counter + 1 : nullptr;      // + per-string executed steps at stats+8 (u32, first 1M strings)
     if (stats) (void)hipMemsetAsync(stats, 0, 16 * sizeof(unsigned long long), s);
-    void* args[] = {(void*)&d_bytes, (void*)&d_offsets, (void*)&n, (void*)&d_results, (void*)&ds.d_counter, (void*)&accel,
-                    (void*)&ds.d_scratch, (void*)&stats};
-    if (ds.timed) (void)hipEventRecord((hipEvent_t)ds.ev_start, s);
+    void* args[] = {(void*)&d_bytes, (void*)&d_offsets, (void*)&n, (void*)&d_results, (void*)&cx.d_counter, (void*)&accel,
+                    (void*)&cx.d_scratch, (void*)&stats, (void*)&d_regions};
+    (void)hipEventRecord((hipEvent_t)cx.ev_start, s);
     e = hipModuleLaunchKernel((hipFunction_t)ds.jit_fn, (unsigned)grid, 1, 1, 64, 1, 1, 0, s, args, nullptr);
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
-    if (ds.timed) (void)hipEventRecord((hipEvent_t)ds.ev_stop, s);
+    (void)hipEventRecord((hipEvent_t)cx.ev_stop, s);
     return MFA_OK;
 }
 
 // debugging aid: copy the counters of the last launch (MFA_STATS=1) to the host and print them
-void jit_print_stats(DeviceState& ds, const char* tag) {
-    if (!getenv("MFA_STATS") || !ds.d_counter) return;
+void jit_print_stats(LaunchCtx& cx, const char* tag) {
+    if (!getenv("MFA_STATS") || !cx.d_counter) return;
     unsigned long long h[17] = {0};
-    if (hipMemcpy(h, ds.d_counter, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (hipMemcpy(h, cx.d_counter, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
     if (const char* path = getenv("MFA_STATS_FILE")) {
         std::vector<uint32_t> steps(1u << 20);
-        if (hipMemcpy(steps.data(), ds.d_counter + 17, steps.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+        if (hipMemcpy(steps.data(), cx.d_counter + 17, steps.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
             FILE* f = fopen(path, "wb");
             if (f) { fwrite(steps.data(), 4, steps.size(), f); fclose(f); }
         }

@@ -183,11 +183,15 @@ struct Gen {
                   << s.F[d] << "), TB);\n";
                 o << ind << "    " << s.F[d] << " = sel(" << rd << ", konst<U>(" << vf << " | F_READ), U(" << s.F[d] << "));\n";
                 o << ind << "    {                                                  // run extent for one-byte-repeated values: found by the whole wave\n";
-                o << ind << "      const bool nr = " << rd << " && uni_needs_run(in, val(i), ch, val(" << vl << "), " << vf << ");\n";
+                o << ind << "      bool nr = " << rd << " && uni_needs_run(in, val(i), ch, val(" << vl << "), " << vf << ");\n";
+                o << ind << "      if (nr && in.rt != nullptr) {                      // the pre-pass knows every long run\n"
+                  << ind << "        uint32_t rh;\n"
+                  << ind << "        if (rt_run<REV>(in, val(i), rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }\n"
+                  << ind << "      }\n";
                 o << ind << "      for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {\n";
                 o << ind << "        const int L = __builtin_ctzll(sb);\n";
-                o << ind << "        const uint32_t r = coop_period_end<REV>(in.bytes, ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L),\n";
-                o << ind << "                                               __shfl(in.len, L), __shfl(val(i), L), 1u, threadIdx.x & 63u);\n";
+                o << ind << "        const uint32_t r = coop_run_end<REV>(in.bytes, ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L),\n";
+                o << ind << "                                            __shfl(in.len, L), __shfl(val(i), L), threadIdx.x & 63u);\n";
                 // a run is a periodic region too: remember it as one, so that the main loop's look does not measure it again
                 // (unless a region that reaches at least as far is already known -- a probe may be relying on it)
                 o << ind << "        if ((threadIdx.x & 63u) == (uint32_t)L) {\n"
@@ -399,7 +403,7 @@ struct Gen {
     std::string run() {
         const uint32_t N = g.h.n_nodes;
         std::vector<std::string> words = slot_words();
-        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_LOOK_EVERY " << knob("MFA_GEN_LOOK_EVERY", 2) << "u\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 8) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
+        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_LOOK_EVERY " << knob("MFA_GEN_LOOK_EVERY", 2) << "u\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 8) << "\n#define MFA_RUN_DEPTH " << knob("MFA_GEN_RUN_DEPTH", 2) << "\n#define MFA_INLINE_SCAN " << knob("MFA_GEN_INLINE_SCAN", 0) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
         o << "\n#define REV " << (rev ? "true" : "false") << "\n#define N_WORDS " << words.size() << "\n#define N_KEYS " << (N - 1) << "\n\n";
         const bool huge = jit_slot_registers(g) > 272;
         const uint32_t lanes = huge ? huge_lanes((uint32_t)words.size()) : 64u;
@@ -461,9 +465,11 @@ struct Gen {
         // ---- kernel
         // small automata: ask for two waves per SIMD (<= 128 VGPRs); the plain step needs far fewer, only the dual
         // step is register hungry and may then spill a little -- it is rare
-        o << "extern \"C\" __global__ void __launch_bounds__(64" << (!huge && (int)words.size() <= knob("MFA_GEN_LB2_WORDS", 20) ? ", 2" : "") << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
+        const int lb_waves = knob("MFA_GEN_WAVES", !huge && (int)words.size() <= knob("MFA_GEN_LB2_WORDS", 20) ? 2 : 0);
+        o << "extern \"C\" __global__ void __launch_bounds__(64" << (lb_waves > 0 ? ", " + num(lb_waves) : std::string()) << ")\nmfa_jit_kernel(const uint8_t* __restrict__ bytes, "
              "const uint64_t* __restrict__ offsets, uint64_t n,\n               uint8_t* __restrict__ results, "
-             "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats_arg) {\n";
+             "unsigned long long* counter, uint32_t accel, uint32_t* __restrict__ scratch, unsigned long long* stats_arg,\n"
+             "               const uint64_t* __restrict__ regions) {\n";
         // the counters cost a dozen VGPRs: they exist only in objects compiled with -DMFA_STATS_BUILD=1 (MFA_STATS=1)
         o << "  unsigned long long* const stats = MFA_STATS_BUILD ? stats_arg : nullptr;\n";
         o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";
@@ -532,7 +538,7 @@ struct Gen {
              "        if (want) {\n          sid = first + (unsigned long long)__builtin_popcountll(wb & ((1ull << lane) - 1ull));\n"
              "          if (sid >= n) exhausted = true;\n          else {\n            const uint64_t b = offsets[sid], e = offsets[sid + 1];\n"
              "            if (e - b > MFA_DEV_MAX_LEN) results[sid] = 2;\n            else {\n"
-             "              len = (uint32_t)(e - b); input_reset(in, b, len);\n"
+             "              len = (uint32_t)(e - b); input_reset(in, b, len); rt_attach(in, regions, sid);\n"
              "              i = 0; accept = false; active = true; phase = 0; probe_at = 0; backoff = 8; pp = 1; fails = 0; mult = 1; nper = 0; stable = false; patient = false;\n";
         for (const auto& w : words)
             o << "              c." << w << " = " << (w == "P" + num(g.h.start) ? "0u" : (w[0] == 'P' ? "MFA_EMPTY" : "0u")) << ";\n";
@@ -545,13 +551,26 @@ struct Gen {
              "    uint32_t q = 0u;\n"
              "    const bool ep_busy = __any(phase != 0u);      // probes run in epochs: all lanes that probe do it in the same iterations\n"
              "    if (accel && active && !final_pass && phase == 0u && i >= probe_at && !ep_busy) {\n"
-             "      uint32_t nb;\n"
-             "      q = block_period<REV>(in, i, nb);\n"
-             "      probe_at = i + (nb < MFA_LOOK_EVERY ? nb : MFA_LOOK_EVERY);      // next look if nothing comes of this one\n"
-             "      if (nb < 8u) q = 0u;\n"
+             "#if MFA_INLINE_SCAN\n"
+             "      if (in.rt == nullptr) {                       // no table: look at the next 16 bytes (round-1 scheme, A/B runs only)\n"
+             "        uint32_t nb;\n"
+             "        q = block_period<REV>(in, i, nb);\n"
+             "        probe_at = i + (nb < MFA_LOOK_EVERY ? nb : MFA_LOOK_EVERY);      // next look if nothing comes of this one\n"
+             "        if (nb < 8u) q = 0u;\n"
+             "      } else\n"
+             "#endif\n"
+             "      if (in.per_q != 0u && in.per_lo <= i && i < in.per_hi) q = in.per_q;      // still inside the region found last\n"
+             "      else if (in.rt != nullptr) {                  // regions come from the pre-pass table (regions.hip): nothing to measure\n"
+             "        uint32_t rl, rh, rq, rn;\n"
+             "        if (rt_find<REV>(in, i, mult, rl, rh, rq, rn)) {\n"
+             "          if (in.per_q != 0u) { in.prev_lo = in.per_lo; in.prev_hi = in.per_hi; in.prev_q = in.per_q; }\n"
+             "          in.per_lo = rl; in.per_hi = rh; in.per_q = rq; q = rq;\n"
+             "        } else probe_at = rn;                       // look again where the next region starts (never, if there is none)\n"
+             "      } else probe_at = ~0u;                        // no table: every step is executed\n"
              "    }\n"
-             "    bool need_scan = q != 0u && !(in.per_q == q && in.per_lo <= i && i < in.per_hi);\n"
              "    const unsigned long long tm0 = stats ? clock64() : 0;\n"
+             "#if MFA_INLINE_SCAN\n"
+             "    bool need_scan = q != 0u && !(in.per_q == q && in.per_lo <= i && i < in.per_hi);\n"
              "    for (unsigned long long sb = __ballot(need_scan); sb; sb &= sb - 1ull) {          // one string at a time, all lanes scanning\n"
              "      const int L = __builtin_ctzll(sb);\n"
              "      const uint64_t sbase = ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L);\n"
@@ -561,6 +580,7 @@ struct Gen {
              "        in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++;\n"
              "      }\n"
              "    }\n"
+             "#endif\n"
              "    if (stats) tm_scan += clock64() - tm0;\n"
              "    if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
              "    if (q != 0u && q * mult > 16u) mult = 1u;\n"

@@ -516,12 +516,12 @@ dfa_tiled_kernel(DfaPacked pk, const uint16_t* __restrict__ trans, const uint8_t
 
 // ---- launchers ------------------------------------------------------------------------------------
 template <int K, bool REV>
-static int launch_mfa_k(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
+static int launch_mfa_k(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                         uint64_t n, uint8_t* d_results, hipStream_t stream) {
     DevImg g{ds.d_edge_begin, ds.d_edges, img.h.n_nodes, img.h.start, img.h.finish, img.h.is_reversed};
     const size_t per_wave = (size_t)2 * img.h.n_nodes * SlotLayout<K>::W * 64 * sizeof(uint32_t);
     const bool lds_slots = per_wave <= 40 * 1024;             // >= 4 waves per CU out of 160 KiB
-    HIP_TRY(hipMemsetAsync(ds.d_counter, 0, sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(cx.d_counter, 0, sizeof(unsigned long long), stream));
     int waves_per_cu = 8;
     if (lds_slots) {
         int by_lds = (int)((160 * 1024) / per_wave);
@@ -532,44 +532,39 @@ static int launch_mfa_k(const HostImage& img, DeviceState& ds, const uint8_t* d_
     if (grid > want) grid = want;
     if (grid == 0) grid = 1;
     if (!lds_slots) {
-        size_t need = (size_t)grid * per_wave;
-        if (need > ds.scratch_bytes) {
-            if (ds.d_scratch) HIP_TRY(hipFree(ds.d_scratch));
-            ds.d_scratch = nullptr; ds.scratch_bytes = 0;
-            HIP_TRY(hipMalloc(&ds.d_scratch, need));
-            ds.scratch_bytes = need;
-        }
+        int rc = ctx_reserve((void**)&cx.d_scratch, &cx.scratch_bytes, (size_t)grid * per_wave);
+        if (rc != MFA_OK) return rc;
     }
-    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_start, stream));
+    HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_start, stream));
     if (lds_slots) {
         auto kern = mfa_walk_kernel<K, REV, true>;
         HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave));
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), per_wave, stream, g, d_bytes, d_offsets, n, d_results,
-                           ds.d_counter, (uint32_t*)nullptr);
+                           cx.d_counter, (uint32_t*)nullptr);
     } else {
         hipLaunchKernelGGL((mfa_walk_kernel<K, REV, false>), dim3((unsigned)grid), dim3(64), 0, stream, g, d_bytes,
-                           d_offsets, n, d_results, ds.d_counter, ds.d_scratch);
+                           d_offsets, n, d_results, cx.d_counter, cx.d_scratch);
     }
     HIP_TRY(hipGetLastError());
-    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_stop, stream));
+    HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_stop, stream));
     return MFA_OK;
 }
 
 template <int K>
-static int launch_mfa_rev(const HostImage& img, DeviceState& ds, const uint8_t* b, const uint64_t* o, uint64_t n,
+static int launch_mfa_rev(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* b, const uint64_t* o, uint64_t n,
                           uint8_t* r, hipStream_t s) {
-    return img.h.is_reversed ? launch_mfa_k<K, true>(img, ds, b, o, n, r, s) : launch_mfa_k<K, false>(img, ds, b, o, n, r, s);
+    return img.h.is_reversed ? launch_mfa_k<K, true>(img, ds, cx, b, o, n, r, s) : launch_mfa_k<K, false>(img, ds, cx, b, o, n, r, s);
 }
 
-int launch_mfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
+int launch_mfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     switch (img.h.n_cells) {
         case 0:
-        case 1: return launch_mfa_rev<1>(img, ds, d_bytes, d_offsets, n, d_results, s);
-        case 2: return launch_mfa_rev<2>(img, ds, d_bytes, d_offsets, n, d_results, s);
-        case 3: return launch_mfa_rev<3>(img, ds, d_bytes, d_offsets, n, d_results, s);
-        case 4: return launch_mfa_rev<4>(img, ds, d_bytes, d_offsets, n, d_results, s);
+        case 1: return launch_mfa_rev<1>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
+        case 2: return launch_mfa_rev<2>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
+        case 3: return launch_mfa_rev<3>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
+        case 4: return launch_mfa_rev<4>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
     }
     return MFA_ERR_UNSUPPORTED;
 }
@@ -592,7 +587,7 @@ static bool make_packed(const HostImage& img, DfaPacked& pk) {
 }
 
 template <bool REV, bool PACKED, int NLIT>
-static int launch_dfa_tiled(const HostImage& img, DeviceState& ds, const DfaPacked& pk, const uint8_t* d_bytes,
+static int launch_dfa_tiled(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const DfaPacked& pk, const uint8_t* d_bytes,
                             const uint64_t* d_offsets, uint64_t n, uint8_t* d_results, hipStream_t s) {
     size_t lds = 4 * 64 * kTileRow + (PACKED ? 0 : (size_t)img.dfa_states * kDfaRow * sizeof(uint16_t));
     uint64_t per_cu = (160u * 1024u) / lds;                 // resident blocks a CU's LDS allows (at most 8: 32 waves)
@@ -603,15 +598,15 @@ static int launch_dfa_tiled(const HostImage& img, DeviceState& ds, const DfaPack
     if (blocks == 0) blocks = 1;
     auto kern = dfa_tiled_kernel<REV, PACKED, NLIT>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_start, s));
+    HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_start, s));
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, pk, ds.d_dfa_trans, ds.d_dfa_accept, ds.d_byte_class,
                        img.dfa_states, img.n_classes, d_bytes, d_offsets, n, d_results);
     HIP_TRY(hipGetLastError());
-    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_stop, s));
+    HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_stop, s));
     return MFA_OK;
 }
 
-int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
+int launch_dfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if ((size_t)img.dfa_states * kDfaRow > 0xffffu) return MFA_ERR_UNSUPPORTED;      // 16-bit pre-multiplied states
@@ -623,7 +618,7 @@ int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_byte
             // untiled 1.0 TB/s -- the LDS table is the default, "packed" selects the SGPR form
             const bool packed = mode && mode[0] == 'p' && make_packed(img, pk);
             if ((size_t)img.dfa_states * kDfaRow * 2 + 4 * 64 * kTileRow <= 64 * 1024) {
-#define MFA_DFA_GO(REVV, P, NL) return launch_dfa_tiled<REVV, P, NL>(img, ds, pk, d_bytes, d_offsets, n, d_results, s)
+#define MFA_DFA_GO(REVV, P, NL) return launch_dfa_tiled<REVV, P, NL>(img, ds, cx, pk, d_bytes, d_offsets, n, d_results, s)
                 if (packed && pk.n_lit <= 4) {
                     if (img.h.is_reversed) {
                         switch (pk.n_lit) { case 0: MFA_DFA_GO(true, true, 0); case 1: MFA_DFA_GO(true, true, 1); case 2: MFA_DFA_GO(true, true, 2);
@@ -645,7 +640,7 @@ int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_byte
     uint64_t cap = (uint64_t)ds.n_cus * 8;
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
-    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_start, s));
+    HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_start, s));
     if (img.h.is_reversed) {
         HIP_TRY(hipFuncSetAttribute((const void*)dfa_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(dfa_walk_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, ds.d_dfa_trans, ds.d_dfa_accept,
@@ -656,7 +651,7 @@ int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_byte
                            ds.d_byte_class, img.dfa_states, img.n_classes, d_bytes, d_offsets, n, d_results);
     }
     HIP_TRY(hipGetLastError());
-    if (ds.timed) HIP_TRY(hipEventRecord((hipEvent_t)ds.ev_stop, s));
+    HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_stop, s));
     return MFA_OK;
 }
 

@@ -37,6 +37,26 @@ int tabulate_nfa(HostImage& img);                                    // fills th
 
 // ---- per-device state -----------------------------------------------------------------------
 
+// Workspace of ONE launch: ticket counter, scratch, region table, events.  Every launch takes one from the
+// pool of its (image, device); a context is reused by a later launch on the SAME stream (stream order makes
+// that safe) or once its `done` event has completed, so launches of one image that overlap on different
+// streams or from different host threads never share a counter, a scratch buffer or an event.
+struct LaunchCtx {
+    unsigned long long* d_counter = nullptr;   // next-string ticket (+ MFA_STATS words)
+    uint32_t*           d_scratch = nullptr;   // slot arrays / probe images that do not fit LDS
+    size_t              scratch_bytes = 0;
+    uint64_t*           d_regions = nullptr;   // region table of the batch (regions.hip)
+    size_t              region_bytes = 0;
+    void*               ev_start = nullptr;    // hipEvent_t: around the match kernel
+    void*               ev_stop  = nullptr;
+    void*               ev_r0 = nullptr;       // around the region pass
+    void*               ev_r1 = nullptr;
+    void*               ev_done = nullptr;     // after the last kernel of the launch (no timing)
+    void*               stream = nullptr;      // stream of the launch it was last used for
+    bool                used = false;
+    bool                ran_regions = false;
+};
+
 struct DeviceState {
     int       device = -1;
     // MFA kind
@@ -46,13 +66,9 @@ struct DeviceState {
     uint16_t* d_dfa_trans  = nullptr;
     uint8_t*  d_dfa_accept = nullptr;
     uint8_t*  d_byte_class = nullptr;
-    // launch workspace
-    unsigned long long* d_counter = nullptr;   // next-string ticket
-    uint32_t*           d_scratch = nullptr;   // slot arrays for automata too large for LDS
-    size_t              scratch_bytes = 0;
-    void*               ev_start = nullptr;    // hipEvent_t
-    void*               ev_stop  = nullptr;
-    bool                timed = false;
+    // launch workspaces
+    std::vector<LaunchCtx*> ctxs;
+    LaunchCtx*              last = nullptr;    // context of the most recent launch (mfa_last_kernel_ms)
     int                 n_cus = 0;
     // specialised kernel (jit.hip), if one is loaded for this device
     bool                jit_tried = false;
@@ -75,10 +91,15 @@ struct mfa_image {
 namespace mfa {
 
 // launchers (kernels.hip); all asynchronous on `stream`
-int launch_mfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
+int launch_mfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream);
-int launch_dfa_walk(const HostImage& img, DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets,
+int launch_dfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream);
+// regions.hip
+int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream);
+// launch contexts (capi.hip); the caller holds the image mutex
+int  ctx_acquire(DeviceState& ds, void* stream, LaunchCtx** out);
+int  ctx_reserve(void** buf, size_t* have, size_t need);
 int device_prepare(mfa_image* img, int device, DeviceState** out);
 // specialised kernels (jit_gen.cpp, jit.hip)
 uint32_t    jit_slot_registers(const HostImage& img);
@@ -88,9 +109,9 @@ bool        jit_enabled(const HostImage& img);
 std::string jit_compile(const HostImage& img, std::string* err);
 bool        jit_load(const HostImage& img, DeviceState& ds);
 void        jit_unload(DeviceState& ds);
-void        jit_print_stats(DeviceState& ds, const char* tag);
-int         launch_mfa_jit(DeviceState& ds, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
-                           void* stream);
+void        jit_print_stats(LaunchCtx& cx, const char* tag);
+int         launch_mfa_jit(DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
+                           const uint64_t* d_regions, void* stream);
 void device_release(DeviceState& ds);
 void set_last_hip_error(int e);
 

@@ -1,0 +1,280 @@
+// Region pre-pass: one streaming read of a batch that finds every string's periodic regions.
+//
+// The specialised walk kernels (jit_gen.cpp) skip over stretches of input that repeat with a short
+// period q <= 8 ("run / period acceleration"); to do that exactly they must know how far such a
+// stretch extends, which is the one place on the path where every input byte has to be looked at
+// (reference: the reads of str[i] in mfa.cpp:163-166 and the substr compares in mfa.cpp:179-191).
+// In round 1 the walk kernels measured the stretches themselves, at 200-256 VGPRs per wave.  This
+// kernel does that reading instead: few registers, full occupancy, every byte of the batch fetched
+// once, and it leaves a small table per string that the walk kernels look regions up in.
+//
+// Definitions (offsets relative to the start of the string, memory order):
+//   d_q[j] = (s[j] != s[j+q])  for 0 <= j < len - q,  q = 1..8
+//   a maximal zero run [a, b) of d_q is the q-periodic REGION [lo, hi) = [a, b + q)
+// Table of a string (MFA_REGION_WORDS u64 words): word 0 = header, then up to MFA_REGION_MAX entries
+//   entry  = lo | hi << 24 | q << 48
+//   header = count | MFA_REGION_OVERFLOW  (overflow: the string has more regions than fit and the table
+//            holds the longest ones, or the string is too long to be matched at all)
+// Guarantees the walk kernels rely on:
+//   (1) every entry is true: s[j] == s[j+q] for lo <= j < hi - q;
+//   (2) entries with q = 1 are maximal at both ends (cell reads of one-byte-repeated values compare
+//       a length with the exact extent of a run, device_common.h: read_pre_u);
+//   (3) without the overflow flag, every maximal region that contains at least kCleanMin + 2 whole
+//       16-byte blocks is in the table unless a region of a divisor period covers it (to within 16
+//       bytes at either end) -- completeness only matters for speed, never for results.
+//
+// How: one wave per string; lane L of row r looks at the 16-byte block 64 r + L of the string (blocks are
+// 16-byte aligned in the batch) plus the 8 bytes behind it, and decides per q whether the block is
+// "dirty" (holds a j with d_q[j] = 1).  A ballot per q gives the dirty blocks of the row; scalar code
+// keeps, per q, the last dirty block seen and records a candidate (q, X, Y) whenever at least kCleanMin
+// clean blocks lie between two dirty ones X < Y.  The exact ends are resolved once per string, all
+// candidates at once (lane e re-reads blocks X and Y of candidate e).  Blocks may be declared dirty
+// without being so ("forced"): block 0 and the blocks that hold the last 8 bytes.  Forcing never breaks
+// (1): the ends are resolved against the real bytes, and a forced block without a real mismatch just
+// ends the region at a block boundary (or at the end of the string).
+// The block test is twelve V_QSAD_PK_U16_U8 (all eight periods at once, see block_mask); a row whose
+// 64 blocks all look like the previous row's costs one compare and one ballot more.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdlib>
+
+#include "mfa_internal.h"
+
+namespace mfa {
+
+#define HIP_TRY(expr)                                                   \
+    do {                                                                \
+        hipError_t e_ = (expr);                                         \
+        if (e_ != hipSuccess) { set_last_hip_error((int)e_); return MFA_ERR_HIP; } \
+    } while (0)
+
+static constexpr int kCleanMin = 4;          // clean 16-byte blocks between two dirty ones that make a candidate
+static constexpr uint32_t kMaxLen = 0x00ffffffu;
+
+// bit k set iff byte k of d is non-zero
+__device__ __forceinline__ uint32_t nz8(uint64_t d) {
+    const uint64_t x = (((d & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | d) & 0x8080808080808080ull;
+    return (uint32_t)(((x >> 7) * 0x0102040810204080ull) >> 56);
+}
+
+// bytes [s, s+8) of the 16 bytes (hi:lo), 0 <= s <= 8
+__device__ __forceinline__ uint64_t shr_bytes(uint64_t lo, uint64_t hi, uint32_t s) {
+    return s == 0u ? lo : (s >= 8u ? hi : (lo >> (8u * s)) | (hi << (64u - 8u * s)));
+}
+
+// ---- the per-block test ---------------------------------------------------------------------------------
+// V_QSAD_PK_U16_U8 compares a 4-byte reference with the four 4-byte windows at byte offsets 0..3 of an 8-byte source and
+// ADDS the four sums of absolute differences to four packed 16-bit accumulators.  With the reference = dword m of the
+// block and the source = the bytes from dword m (or m + 1) on, one instruction yields, for that dword, the mismatch sums
+// for the periods 0..3 (or 4..7); four of them cover a 16-byte block.  A sum is zero iff no byte of the block differs
+// from the byte q behind it.  (Sums stay below 16 * 255: no carry between the 16-bit fields.)
+__device__ __forceinline__ uint64_t qsad(uint32_t src_lo, uint32_t src_hi, uint32_t ref, uint64_t acc) {
+    return __builtin_amdgcn_qsad_pk_u16_u8(((uint64_t)src_hi << 32) | src_lo, ref, acc);
+}
+__device__ __forceinline__ uint32_t pk_nz(uint32_t d) {               // both 16-bit halves -> 0 / 1
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(d), "v"(0x00010001u));
+    return r;
+}
+
+// bit of period q in a lane's block mask (set = the block is dirty for q)
+__device__ __forceinline__ constexpr uint32_t qbit(int q) {
+    return q == 1 ? 1u << 16 : q == 2 ? 1u << 1 : q == 3 ? 1u << 17 : q == 4 ? 1u << 2 : q == 5 ? 1u << 18 : q == 6 ? 1u << 3 : q == 7 ? 1u << 19 : 1u << 4;
+}
+static constexpr uint32_t kAllDirty = 0x000f001eu;
+
+__device__ __forceinline__ uint32_t block_mask(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, uint32_t w4, uint32_t w5) {
+    uint64_t a = 0, b = 0;
+    a = qsad(w0, w1, w0, a); a = qsad(w1, w2, w1, a); a = qsad(w2, w3, w2, a); a = qsad(w3, w4, w3, a);      // periods 0..3
+    b = qsad(w1, w2, w0, b); b = qsad(w2, w3, w1, b); b = qsad(w3, w4, w2, b); b = qsad(w4, w5, w3, b);      // periods 4..7
+    const uint32_t d8 = (w0 ^ w2) | (w1 ^ w3) | (w2 ^ w4) | (w3 ^ w5);                                    // period 8
+    const uint32_t z0 = pk_nz((uint32_t)a), z1 = pk_nz((uint32_t)(a >> 32)), z2 = pk_nz((uint32_t)b), z3 = pk_nz((uint32_t)(b >> 32));
+    const uint32_t z8 = d8 < 1u ? d8 : 1u;
+    return ((z0 | (z1 << 1)) | ((z2 << 2) | (z3 << 3)) | (z8 << 4)) & kAllDirty;      // & drops the period-0 field
+}
+
+struct RegionState {
+    int32_t  last_dirty[9];      // per period: the last dirty block seen (scalar registers after unrolling)
+    uint32_t ncand;              // candidates recorded so far (wave-uniform)
+    // candidate e lives in lane e
+    uint32_t cq;
+    int32_t  cx, cy;
+};
+
+__device__ __forceinline__ void emit(RegionState& st, uint32_t lane, uint32_t q, int32_t x, int32_t y) {
+    if (lane == st.ncand) { st.cq = q; st.cx = x; st.cy = y; }
+    st.ncand++;
+}
+
+// book-keeping of one row for one period: dirty = ballot of dirty blocks, base = block number of lane 0
+template <int Q>
+__device__ __forceinline__ void book(RegionState& st, uint32_t lane, unsigned long long dirty, int32_t base) {
+    int32_t& last = st.last_dirty[Q];
+    if (dirty == ~0ull && last == base - 1) { last = base + 63; return; }      // nothing clean anywhere: the common dirty case
+    if (dirty == 0ull) return;
+    const int32_t first = (int32_t)__builtin_ctzll(dirty), top = 63 - (int32_t)__builtin_clzll(dirty);
+    if (base + first - last - 1 >= kCleanMin) emit(st, lane, Q, last, base + first);
+    // clean stretches between dirty blocks of this row
+    unsigned long long z = ~dirty;
+    unsigned long long zz = z;
+#pragma unroll
+    for (int k = 1; k < kCleanMin; k++) zz &= z >> k;
+    const unsigned long long inside = first < top ? ((~0ull >> (63 - top)) & (~0ull << first)) : 0ull;
+    if (zz & inside) {
+        int32_t prev = first;
+        for (unsigned long long m = dirty & (dirty - 1ull); m; m &= m - 1ull) {
+            const int32_t nxt = (int32_t)__builtin_ctzll(m);
+            if (nxt - prev - 1 >= kCleanMin) emit(st, lane, Q, base + prev, base + nxt);
+            prev = nxt;
+        }
+    }
+    last = base + top;
+}
+
+template <int Q>
+__device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, uint32_t mask, uint32_t settled, int32_t base) {
+    if (settled & qbit(Q)) st.last_dirty[Q] = base - 1;        // every block of the rows skipped before this one was dirty
+    book<Q>(st, lane, __ballot((mask & qbit(Q)) != 0u), base);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
+                                                          uint64_t* __restrict__ table) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4u;
+    const uint64_t total16 = (offsets[n] + 15u) & ~(uint64_t)15;        // the batch is readable below this offset
+    for (uint64_t sid = wave; sid < n; sid += n_waves) {
+        const uint64_t b = offsets[sid], e = offsets[sid + 1];
+        uint64_t* const tab = table + sid * MFA_REGION_WORDS;
+        if (e - b > kMaxLen) { if (lane == 0) tab[0] = MFA_REGION_OVERFLOW; continue; }
+        const uint32_t len = (uint32_t)(e - b);
+        const uint64_t a0 = b & ~(uint64_t)15;
+        const uint32_t off0 = (uint32_t)(b - a0);
+        const int32_t nblk = (int32_t)((off0 + len + 15u) >> 4);
+        const int32_t endblk = len >= 8u ? (int32_t)((off0 + len - 8u) >> 4) : 0;
+        RegionState st;
+#pragma unroll
+        for (int q = 0; q < 9; q++) st.last_dirty[q] = -1;
+        st.ncand = 0; st.cq = 0; st.cx = 0; st.cy = 0;
+        // Rows whose blocks all carry the same mask as the row before (a stretch inside one periodic region, or text in which
+        // every block is dirty for every period) need no book-keeping at all: one compare and one ballot.  `settled` is that
+        // mask (~0u: the last row was not uniform); the dirty periods' last_dirty is caught up when the stretch ends.
+        uint32_t settled = ~0u;
+        // no branch around the loads (the compiler then counts them and waits for the older pair only): rows are read whole,
+        // lanes past the last block re-read it, and the 8 bytes behind the very last block of the batch come from inside it;
+        // what such lanes load is never looked at (their blocks are forced)
+        const uint64_t ymax = total16 - 8u;
+        auto load_row = [&](int32_t row, uint4& x, uint2& y) {
+            int32_t blk = row * 64 + (int32_t)lane;
+            blk = blk < nblk ? blk : nblk - 1;
+            const uint64_t addr = a0 + 16u * (uint64_t)blk;
+            const uint64_t ya = addr + 16u <= ymax ? addr + 16u : ymax;
+            x = *reinterpret_cast<const uint4*>(bytes + addr);
+            y = *reinterpret_cast<const uint2*>(bytes + ya);
+        };
+        uint4 x, nx;
+        uint2 y, ny;
+        load_row(0, x, y);
+        for (int32_t row = 0; row * 64 < nblk; row++) {
+            load_row((row + 1) * 64 < nblk ? row + 1 : row, nx, ny);       // the next row is on its way while this one is looked at
+            const int32_t base = row * 64, blk = base + (int32_t)lane;
+            const bool forced = blk == 0 || blk >= endblk;
+            const uint32_t mask = forced ? kAllDirty : block_mask(x.x, x.y, x.z, x.w, y.x, y.y);
+            x = nx; y = ny;
+            if (__all(mask == settled)) continue;
+            const uint32_t was = settled != ~0u ? settled : 0u;
+            row_period<1>(st, lane, mask, was, base);
+            row_period<2>(st, lane, mask, was, base);
+            row_period<3>(st, lane, mask, was, base);
+            row_period<4>(st, lane, mask, was, base);
+            row_period<5>(st, lane, mask, was, base);
+            row_period<6>(st, lane, mask, was, base);
+            row_period<7>(st, lane, mask, was, base);
+            row_period<8>(st, lane, mask, was, base);
+            const uint32_t m0 = __builtin_amdgcn_readfirstlane(mask);
+            settled = __all(mask == m0) ? m0 : ~0u;
+        }
+        if (MODE == 1) { if (lane == 0) tab[0] = st.ncand; continue; }            // experiment: streaming phase only
+        // ---- exact ends: lane c resolves candidate c against the real bytes
+        const uint32_t ncand = st.ncand < 64u ? st.ncand : 64u;
+        bool keep = false;
+        uint32_t lo = 0, hi = 0;
+        const uint32_t q = st.cq;
+        if (lane < ncand) {
+            const int64_t vlo = (int64_t)off0, vhi = (int64_t)off0 + (int64_t)len - (int64_t)q;   // valid j (relative to a0): vlo <= j < vhi
+            auto ld8 = [&](uint64_t addr) -> uint64_t {
+                uint64_t v = 0;
+                if (addr + 8u <= total16) v = *reinterpret_cast<const uint64_t*>(bytes + addr);
+                return v;
+            };
+            {   // the last real mismatch in block X, or the first valid position of X
+                const uint64_t addr = a0 + 16u * (uint64_t)st.cx;
+                const uint64_t p0 = ld8(addr), p1 = ld8(addr + 8u), p2 = ld8(addr + 16u);
+                uint32_t m = nz8(p0 ^ shr_bytes(p0, p1, q)) | (nz8(p1 ^ shr_bytes(p1, p2, q)) << 8);
+                const int64_t w0 = 16 * (int64_t)st.cx;
+                uint32_t valid = 0xffffu;
+                if (vlo > w0) valid &= vlo - w0 >= 16 ? 0u : (0xffffu << (uint32_t)(vlo - w0));
+                if (vhi < w0 + 16) valid &= vhi <= w0 ? 0u : (0xffffu >> (uint32_t)(w0 + 16 - vhi));
+                m &= valid;
+                const int64_t lo_abs = m ? w0 + (31 - __builtin_clz(m)) + 1 : (w0 > vlo ? w0 : vlo);
+                lo = (uint32_t)(lo_abs - vlo);
+            }
+            {   // the first real mismatch in blocks Y, Y + 1
+                const uint64_t addr = a0 + 16u * (uint64_t)st.cy;
+                const uint64_t p0 = ld8(addr), p1 = ld8(addr + 8u), p2 = ld8(addr + 16u), p3 = ld8(addr + 24u), p4 = ld8(addr + 32u);
+                uint32_t m = nz8(p0 ^ shr_bytes(p0, p1, q)) | (nz8(p1 ^ shr_bytes(p1, p2, q)) << 8) | (nz8(p2 ^ shr_bytes(p2, p3, q)) << 16) |
+                             (nz8(p3 ^ shr_bytes(p3, p4, q)) << 24);
+                const int64_t w0 = 16 * (int64_t)st.cy;
+                uint32_t valid = 0xffffffffu;
+                if (vhi < w0 + 32) valid = vhi <= w0 ? 0u : (0xffffffffu >> (uint32_t)(w0 + 32 - vhi));
+                m &= valid;
+                int64_t hi_abs;
+                if (m) hi_abs = w0 + __builtin_ctz(m) + (int64_t)q;
+                else if (vhi < w0 + 32) hi_abs = vlo + (int64_t)len;
+                else hi_abs = w0 + 32 + (int64_t)q;
+                hi = (uint32_t)(hi_abs - vlo);
+            }
+            keep = hi > lo && hi - lo >= MFA_REGION_MIN_LEN && hi <= len;
+        }
+        // ---- drop regions that a region of a divisor period covers
+        for (uint32_t f = 0; f < ncand; f++) {
+            const uint32_t qf = __shfl(q, (int)f), lof = __shfl(lo, (int)f), hif = __shfl(hi, (int)f);
+            const bool kf = __shfl((int)keep, (int)f) != 0;
+            if (!kf) continue;
+            const bool divides = ((0x804020108824aaffull >> (((qf - 1u) * 8u + (q - 1u)) & 63u)) & 1ull) != 0ull;     // bit 8 (qf-1) + (q-1): qf divides q
+            if (lane < ncand && lane != f && qf < q && divides && lof <= lo + 16u && hif + 16u >= hi) keep = false;
+        }
+        unsigned long long kb = __ballot(keep);
+        const uint32_t total = (uint32_t)__builtin_popcountll(kb);
+        if (total > MFA_REGION_MAX) {                          // more than fit: the longest stay
+            const uint32_t mine = hi - lo;
+            uint32_t longer = 0;
+            for (uint32_t f = 0; f < ncand; f++) {
+                const uint32_t lf = __shfl(mine, (int)f);
+                if (((kb >> f) & 1ull) && (lf > mine || (lf == mine && f < lane))) longer++;
+            }
+            keep = keep && longer < MFA_REGION_MAX;
+            kb = __ballot(keep);
+        }
+        const uint32_t rank = (uint32_t)__builtin_popcountll(kb & ((1ull << lane) - 1ull));
+        if (keep && rank < MFA_REGION_MAX) tab[1 + rank] = (uint64_t)lo | ((uint64_t)hi << 24) | ((uint64_t)q << 48);
+        if (lane == 0) tab[0] = (uint64_t)(total < MFA_REGION_MAX ? total : MFA_REGION_MAX) |
+                                ((total > MFA_REGION_MAX || st.ncand > 64u) ? MFA_REGION_OVERFLOW : 0ull);
+    }
+}
+
+int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream) {
+    if (n == 0) return MFA_OK;
+    uint64_t blocks = (n + 3) / 4;
+    const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * 8u * 64u;      // beyond this waves take several strings each
+    if (blocks > cap) blocks = cap;
+    const char* em = getenv("MFA_REGION_MODE");                   // development: 1 = streaming phase only
+    if (const char* ec = getenv("MFA_REGION_CAP")) { const uint64_t c = (uint64_t)atoll(ec); if (c > 0 && blocks > c) blocks = c; }
+    if (em && atoi(em) == 1) hipLaunchKernelGGL((region_scan_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_bytes, d_offsets, n, d_table);
+    else hipLaunchKernelGGL((region_scan_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_bytes, d_offsets, n, d_table);
+    HIP_TRY(hipGetLastError());
+    return MFA_OK;
+}
+
+}  // namespace mfa

@@ -15,8 +15,10 @@ KERNEL_NONE, KERNEL_GENERIC, KERNEL_SPECIALISED, KERNEL_TABLE = 0, 1, 2, 3
 ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_TOO_LONG, ERR_JIT = -1, -2, -3, -4, -5, -6, -7, -8
 
 EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_image_specialize", "mfa_match_batch",
-           "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_device_count", "mfa_last_hip_error", "mfa_strerror",
-           "mfa_version"]
+           "mfa_match_batch_regions", "mfa_region_scan", "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_last_region_ms",
+           "mfa_device_count", "mfa_last_hip_error", "mfa_strerror", "mfa_version"]
+
+REGION_WORDS, REGION_MAX, REGION_OVERFLOW, REGION_MIN_LEN = 16, 15, 0x100, 64
 
 
 class MfaError(RuntimeError):
@@ -59,6 +61,9 @@ def lib():
         L.mfa_image_prepare.argtypes = [vp, i32]
         L.mfa_image_specialize.argtypes = [vp]
         L.mfa_match_batch.argtypes = [vp, vp, vp, u64, vp, i32, vp]
+        L.mfa_match_batch_regions.argtypes = [vp, vp, vp, u64, vp, vp, i32, vp]
+        L.mfa_region_scan.argtypes = [vp, vp, u64, vp, i32, vp]
+        L.mfa_last_region_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
         L.mfa_match_batch_host.argtypes = [vp, vp, vp, u64, vp, i32]
         L.mfa_last_kernel_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
         L.mfa_strerror.argtypes = [i32]
@@ -115,6 +120,25 @@ class Image:
         self.match_device(d_bytes.data_ptr(), d_offsets.data_ptr(), n, d_results.data_ptr(), dev, s.cuda_stream)
         return d_results[:n]
 
+    def match_tensors_regions(self, d_bytes, d_offsets, d_table, d_results=None, stream=None):
+        """mfa_match_batch_regions: like match_tensors, with a region table the caller has filled (region_scan) for
+        exactly these strings; d_table None = no table (every step is executed)."""
+        import torch
+        n = d_offsets.numel() - 1
+        dev = d_offsets.device.index or 0
+        if d_results is None:
+            d_results = torch.empty(max(n, 1), dtype=torch.uint8, device=d_offsets.device)
+        s = stream if stream is not None else torch.cuda.current_stream(d_offsets.device)
+        _check(lib().mfa_match_batch_regions(self._h, d_bytes.data_ptr(), d_offsets.data_ptr(), n, d_results.data_ptr(),
+                                             d_table.data_ptr() if d_table is not None else None, dev,
+                                             ctypes.c_void_p(s.cuda_stream)), "mfa_match_batch_regions")
+        return d_results[:n]
+
+    def last_region_ms(self, device=0):
+        ms = ctypes.c_float()
+        _check(lib().mfa_last_region_ms(self._h, device, ctypes.byref(ms)), "mfa_last_region_ms")
+        return ms.value
+
     def match_host(self, data, offsets, device=0):
         """numpy uint8 data + uint64 offsets(n+1) in host memory -> numpy uint8 results."""
         import numpy as np
@@ -139,6 +163,19 @@ class Image:
             self.close()
         except Exception:
             pass
+
+
+def region_scan(d_bytes, d_offsets, d_table=None, stream=None):
+    """mfa_region_scan on torch CUDA tensors: returns the region table, int64 [n, REGION_WORDS]."""
+    import torch
+    n = d_offsets.numel() - 1
+    dev = d_offsets.device.index or 0
+    if d_table is None:
+        d_table = torch.empty((max(n, 1), REGION_WORDS), dtype=torch.int64, device=d_offsets.device)
+    s = stream if stream is not None else torch.cuda.current_stream(d_offsets.device)
+    _check(lib().mfa_region_scan(d_bytes.data_ptr(), d_offsets.data_ptr(), n, d_table.data_ptr(), dev,
+                                 ctypes.c_void_p(s.cuda_stream)), "mfa_region_scan")
+    return d_table
 
 
 def device_count():

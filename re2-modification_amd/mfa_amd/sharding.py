@@ -24,13 +24,21 @@ def partition_by_bytes(offsets, world):
 
 
 def pack_bitmap(results):
-    """torch uint8 0/1 tensor (n) -> uint8 bitmap (ceil(n/8)), bit k%8 of byte k//8 = string k."""
+    """torch uint8 result tensor (n; 1 = accepted, 0 = rejected, 2 = not matched: longer than the device limit) -> uint8 bitmap
+    (ceil(n/8)), bit k%8 of byte k//8 = string k accepted.  Only the value 1 sets a bit; count_unmatched() reports the 2s."""
     import torch
     n = results.numel()
+    r = (results == 1).to(torch.uint8)
     pad = (-n) % 8
-    r = torch.cat([results, results.new_zeros(pad)]) if pad else results
+    if pad:
+        r = torch.cat([r, r.new_zeros(pad)])
     w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=results.device)
     return (r.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8)
+
+
+def count_unmatched(results):
+    """strings the device refused (result code 2: longer than MFA_MAX_STRING_BYTES)"""
+    return int((results > 1).sum().item())
 
 
 def unpack_bitmap(bitmap, n):
@@ -40,12 +48,15 @@ def unpack_bitmap(bitmap, n):
     return bits.reshape(-1)[:n].to(torch.uint8)
 
 
-def gather_results(local_results, counts, dist, rank, world, dst=0):
+def gather_results(local_results, counts, dist, rank, world, dst=0, comm_device=None):
     """Gather every rank's 0/1 results to `dst` as bitmaps; returns the full result vector there (None
-    elsewhere).  counts[r] = number of strings of rank r (known from the partition)."""
+    elsewhere).  counts[r] = number of strings of rank r (known from the partition).  comm_device: where the
+    collective's buffers live (the GPU for RCCL; "cpu" for gloo)."""
     import torch
     max_bytes = (max(int(c) for c in counts) + 7) // 8
     bm = pack_bitmap(local_results)
+    if comm_device is not None:
+        bm = bm.to(comm_device)
     if bm.numel() < max_bytes:                      # gather needs equal sizes
         bm = torch.cat([bm, bm.new_zeros(max_bytes - bm.numel())])
     if world == 1:

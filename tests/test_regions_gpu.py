@@ -1,0 +1,229 @@
+"""Region pre-pass (re2-modification_amd/csrc/regions.hip) against a numpy restatement of its definition, and the
+launch-context pool behind the C-ABI's re-entrancy promise (include/mfa_hip.h).
+
+The table is an aid of the walk kernels, so what is checked is what they rely on: every entry is a true
+periodic region, q = 1 entries are exactly the maximal runs, long runs are all there."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from mfa_amd import capi, corpus, image
+
+pytestmark = pytest.mark.gpu
+
+
+def true_regions(s, q):
+    """maximal q-periodic regions [lo, hi) of the byte string s (numpy uint8): zero runs of s[j] != s[j+q]"""
+    n = len(s)
+    if n <= q:
+        return []
+    d = np.concatenate(([1], (s[:-q] != s[q:]).astype(np.int8), [1]))
+    edges = np.flatnonzero(np.diff(d))
+    return [(int(a), int(b) + q) for a, b in zip(edges[0::2], edges[1::2])]
+
+
+def scan(strings, pad=0):
+    """region tables of `strings`; `pad` shifts the whole batch so that strings start at every alignment"""
+    import torch
+    data, off = oracle_lib.pack(strings)
+    d_bytes = torch.zeros(pad + len(data) + 64, dtype=torch.uint8, device="cuda")
+    d_bytes[pad:pad + len(data)] = torch.from_numpy(data.copy())
+    d_off = torch.from_numpy(off.astype(np.int64) + pad).cuda()
+    tab = capi.region_scan(d_bytes, d_off)
+    torch.cuda.synchronize()
+    return tab.cpu().numpy().astype(np.uint64)
+
+
+def decode(row):
+    cnt = int(row[0]) & 0xff
+    assert cnt <= capi.REGION_MAX
+    out = []
+    for w in row[1:1 + cnt]:
+        w = int(w)
+        out.append((w & 0xffffff, (w >> 24) & 0xffffff, (w >> 48) & 15))
+    return out, bool(int(row[0]) & capi.REGION_OVERFLOW)
+
+
+def check_tables(strings, tabs):
+    n_entries = 0
+    for s, row in zip(strings, tabs):
+        a = np.frombuffer(s, dtype=np.uint8)
+        entries, overflow = decode(row)
+        n_entries += len(entries)
+        for lo, hi, q in entries:
+            assert 1 <= q <= 8 and lo < hi <= len(a) and hi - lo >= capi.REGION_MIN_LEN, (lo, hi, q, len(a))
+            assert np.array_equal(a[lo:hi - q], a[lo + q:hi]), ("not periodic", lo, hi, q, s[:80])
+            if q == 1:                                  # maximal at both ends
+                assert lo == 0 or a[lo - 1] != a[lo], ("run not maximal at lo", lo, hi, s[:80])
+                assert hi == len(a) or a[hi] != a[hi - 1], ("run not maximal at hi", lo, hi, s[:80])
+        if overflow:
+            continue
+        have = set(entries)
+        for lo, hi in true_regions(a, 1):
+            if hi - lo >= 128:
+                assert (lo, hi, 1) in have, ("long run missing", lo, hi, entries[:6], s[:80])
+        # longer periods: what a divisor's region covers may be dropped or cut; the rest must be there, up to short edges
+        for q in range(2, 9):
+            for lo, hi in true_regions(a, q):
+                if hi - lo < 512:
+                    continue
+                cov = np.zeros(hi - lo, dtype=bool)
+                for l2, h2, q2 in entries:
+                    if q % q2 == 0:
+                        cov[max(l2, lo) - lo:max(min(h2, hi), lo) - lo] = True
+                gaps = np.flatnonzero(np.diff(np.concatenate(([1], cov.astype(np.int8), [1]))))
+                worst = max([int(b - a2) for a2, b in zip(gaps[0::2], gaps[1::2])], default=0)
+                assert worst <= 160, ("long stretch of a region uncovered", q, lo, hi, worst, entries[:8], s[:80])
+    return n_entries
+
+
+def _fuzz_strings(rng, count, max_len):
+    out = []
+    for k in range(count):
+        kind = k % 5
+        target = int(rng.integers(0, max_len))
+        s = bytearray()
+        if kind == 0:                                   # concatenated periodic stretches
+            while len(s) < target:
+                q = int(rng.integers(1, 9))
+                word = bytes(rng.choice(list(b"abc"), size=q).tolist())
+                s += word * int(rng.integers(1, max(2, target // q // int(rng.integers(1, 5)) + 1)))
+                if rng.random() < 0.4:
+                    s += bytes([int(rng.choice(list(b"abcd")))])
+        elif kind == 1:                                 # random text
+            s += bytes(rng.choice(list(b"ab"), size=target).tolist())
+        elif kind == 2:                                 # one byte repeated, a little damage
+            s += b"a" * target
+            for _ in range(int(rng.integers(0, 4))):
+                if s:
+                    s[int(rng.integers(0, len(s)))] = ord("b")
+        elif kind == 3:                                 # runs of random lengths around the table's threshold
+            while len(s) < target:
+                s += bytes([int(rng.choice(list(b"ab")))]) * int(rng.integers(1, 200))
+        else:                                           # attack strings of the corpus
+            ex = int(rng.integers(1, 11))
+            regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+            s += (prefix + corpus.pumped_string(max(target, 8), pump) + (suffix if k % 2 else "")).encode()
+        out.append(bytes(s[:max_len]))
+    return out
+
+
+@pytest.mark.parametrize("pad", [0, 5, 15])
+def test_region_tables(pad):
+    rng = np.random.default_rng(4242 + pad)
+    strings = [b"", b"a", b"ab", b"a" * 63, b"a" * 64, b"a" * 65, b"a" * 200, b"ab" * 100, b"abcabcab" * 40, b"x" + b"a" * 300 + b"y" + b"a" * 300]
+    strings += _fuzz_strings(rng, 400, 5000)
+    strings += _fuzz_strings(rng, 40, 70000)
+    tabs = scan(strings, pad)
+    assert check_tables(strings, tabs) > 300
+
+
+def test_region_table_overflow_keeps_true_regions():
+    """more long regions than a table holds: flagged, and what is kept is still true"""
+    s = b"".join(bytes([97 + (k % 3)]) * 150 for k in range(60))
+    t = b"".join((b"ab" if k % 2 else b"cd") * 100 for k in range(40))
+    tabs = scan([s, t, b"a" * 1000])
+    e0, o0 = decode(tabs[0])
+    e1, o1 = decode(tabs[1])
+    e2, o2 = decode(tabs[2])
+    assert o0 and o1 and not o2 and len(e0) >= 8 and len(e1) >= 8 and e2 == [(0, 1000, 1)]
+    check_tables([s, t, b"a" * 1000], tabs)
+
+
+def _big_batch(ex, n, seed, lo=512, hi=8192):
+    import torch
+    sizes = corpus.pump_sizes(n, seed, lo, hi)
+    ws = (np.arange(n) % 2) == 0
+    d_bytes, d_off = corpus.device_batch(ex, sizes, ws, torch.device("cuda", 0))
+    return d_bytes, d_off, sizes, ws
+
+
+def test_one_image_two_streams_back_to_back():
+    """ONE image, two streams, two large different batches launched back to back: every launch has its own ticket
+    counter, scratch, region table and events, so the overlapping kernels cannot take each other's strings."""
+    import torch
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex6_plain"))
+    img = capi.Image(blob)
+    n = 60000
+    ba, oa, sza, wsa = _big_batch(6, n, 11)
+    bb, ob, szb, wsb = _big_batch(6, n, 22)
+    want_a = img.match_tensors(ba, oa).clone()
+    want_b = img.match_tensors(bb, ob).clone()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(3):
+        ra = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+        rb = torch.full((n,), 7, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()
+        img.match_tensors(ba, oa, ra, stream=s1)
+        img.match_tensors(bb, ob, rb, stream=s2)
+        img.match_tensors(bb, ob, rb, stream=s2)            # the same stream again: its context is reused in stream order
+        torch.cuda.synchronize()
+        assert torch.equal(ra, want_a) and torch.equal(rb, want_b)
+    # anchor: the short strings of batch a against the CPU restatement
+    short = [k for k in range(n) if sza[k] <= 1500][:60]
+    strings = corpus.host_strings(6, sza[short], wsa[short])
+    assert list(want_a[short].cpu().numpy()) == list(oracle_lib.OracleImage(blob).match(strings))
+
+
+def test_one_image_two_host_threads():
+    """the same from two host threads, each with its own stream"""
+    import torch
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex3_plain"))
+    img = capi.Image(blob)
+    n = 40000
+    batches = [_big_batch(3, n, 100 + t) for t in range(2)]
+    want = []
+    for b, o, _, _ in batches:
+        want.append(img.match_tensors(b, o).clone())
+    torch.cuda.synchronize()
+    got = [None, None]
+    errs = []
+
+    def work(t):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            b, o, _, _ = batches[t]
+            for _ in range(4):
+                r = torch.full((n,), 9, dtype=torch.uint8, device="cuda")
+                img.match_tensors(b, o, r, stream=st)
+                st.synchronize()
+                got[t] = r
+                if not torch.equal(r, want[t]):
+                    errs.append("thread %d: results differ" % t)
+        except Exception as e:                                # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    sz, ws = batches[0][2], batches[0][3]
+    short = [k for k in range(n) if sz[k] <= 1500][:60]
+    strings = corpus.host_strings(3, sz[short], ws[short])
+    assert list(want[0][short].cpu().numpy()) == list(oracle_lib.OracleImage(blob).match(strings))
+
+
+def test_shared_region_table_for_several_automata():
+    """mfa_match_batch_regions: one region pass, several automata over the same strings (and a sub-range of them)"""
+    import torch
+    n = 3000
+    d_bytes, d_off, sizes, ws = _big_batch(2, n, 5, 200, 3000)
+    tab = capi.region_scan(d_bytes, d_off)
+    for name in ("ex2_plain", "ex2_reverse", "ex9_plain"):
+        blob = image.blob_from_dump(oracle_lib.load_dump(name))
+        img = capi.Image(blob)
+        own = img.match_tensors(d_bytes, d_off).clone()
+        shared = img.match_tensors_regions(d_bytes, d_off, tab).clone()
+        none = img.match_tensors_regions(d_bytes, d_off, None).clone()
+        part = img.match_tensors_regions(d_bytes, d_off[1000:2001].clone(), tab[1000:2000]).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(own, shared) and torch.equal(own, none) and torch.equal(own[1000:2000], part), name
+        short = [k for k in range(n) if sizes[k] <= 900][:40]
+        strings = corpus.host_strings(2, sizes[short], ws[short])
+        assert list(own[short].cpu().numpy()) == list(oracle_lib.OracleImage(blob).match(strings)), name

@@ -65,3 +65,11 @@ def test_bitmap_roundtrip():
     for n in (0, 1, 7, 8, 9, 1001):
         r = (torch.arange(n) % 3 == 0).to(torch.uint8)
         assert torch.equal(sharding.unpack_bitmap(sharding.pack_bitmap(r), n), r)
+
+
+def test_bitmap_ignores_unmatched_code():
+    """result code 2 (string longer than the device limit) is not an accept and must not leak into a neighbour's bit"""
+    r = torch.tensor([1, 2, 0, 1, 2, 2, 1, 0, 2, 1], dtype=torch.uint8)
+    bm = sharding.pack_bitmap(r)
+    assert torch.equal(sharding.unpack_bitmap(bm, 10), (r == 1).to(torch.uint8))
+    assert sharding.count_unmatched(r) == 4
