@@ -362,11 +362,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--walk-streams", type=int, default=3, help="HIP streams the ten walk launches of a step are spread over")
-    ap.add_argument("--region-launches", choices=["per-example", "one"], default="per-example",
-                    help="region pre-pass: one launch per example (walks start as soon as their example is scanned) or one over the whole batch")
+    ap.add_argument("--region-streams", type=int, default=1, help="HIP streams the region launches alternate between (the tail of one launch overlaps the start of the next)")
+    ap.add_argument("--region-priority", type=int, default=0, help="stream priority of the region streams (-1 = high)")
+    ap.add_argument("--region-launches", default="3",
+                    help="region pre-pass launches per step: 'per-example' (10), 'one', or a number g: the examples, laid out in the batch "
+                         "costliest walk first, are scanned in g launches of consecutive examples; the walks of a group start when "
+                         "their group is scanned and run beside the next group's scan")
     ap.add_argument("--walk-waves", type=int, default=0, help="development: cap the walk kernels at this many waves per CU (MFA_WALK_WAVES_PER_CU)")
     ap.add_argument("--exp", default="", help="development: 'region-only' skips the walk launches")
-    ap.add_argument("--order", default="", help="comma-separated example order of a step (default: costliest walk first, measured in set-up)")
+    ap.add_argument("--order", default="", help="comma-separated order of the examples' segments in the batch (default: costliest walk first)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -405,7 +409,10 @@ def main():
     shards = {}
     n_per = args.strings_per_example
     parts_b, parts_o, pos_s, pos_b = [], [], 0, 0
-    for ex in sorted(corpus.EXAMPLES):
+    # segment order in the batch: costliest walk first (measured once on MI355X; any order is correct)
+    layout = [int(x) for x in args.order.split(",")] if args.order else [2, 5, 3, 8, 9, 10, 6, 4, 1, 7]
+    assert sorted(layout) == sorted(corpus.EXAMPLES)
+    for ex in layout:
         seed = 0x5EED0004 + 1000 * rank + ex
         sizes = corpus.pump_sizes(n_per, seed, args.min_len, args.max_len)
         with_suffix = (np.arange(n_per) % 2) == 0
@@ -430,69 +437,74 @@ def main():
     results = torch.zeros(total_strings, dtype=torch.uint8, device=device)
 
     main_s = torch.cuda.current_stream(device)
-    region_s = torch.cuda.Stream(device)
+    region_pool = [torch.cuda.Stream(device, priority=args.region_priority) for _ in range(max(1, args.region_streams))]
+    region_s = region_pool[0]
     walk_pool = [torch.cuda.Stream(device) for _ in range(max(1, args.walk_streams))]
     ev_fork = torch.cuda.Event(enable_timing=True)
     ev_join = torch.cuda.Event(enable_timing=True)
-    ev_r0 = {ex: torch.cuda.Event(enable_timing=True) for ex in shards}
-    ev_r1 = {ex: torch.cuda.Event(enable_timing=True) for ex in shards}
     ev_done = {ex: torch.cuda.Event() for ex in shards}
-    ev_rall0, ev_rall1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def seg(ex):
         a = shards[ex]["first"]
         return a, a + shards[ex]["n"]
 
-    def launch_all(order, where):
-        """one pass over the mixed batch: region pre-pass per example on the region stream, each example's walk on its stream
-        as soon as its regions are known"""
+    n_groups = {"per-example": len(layout), "one": 1}.get(args.region_launches) or max(1, min(len(layout), int(args.region_launches)))
+    # groups of consecutive examples with about equal bytes
+    groups, acc, cur = [], 0, []
+    for ex in layout:
+        cur.append(ex)
+        acc += shards[ex]["nbytes"]
+        if acc >= total_bytes * (len(groups) + 1) / n_groups - 1 and len(groups) < n_groups - 1:
+            groups.append(cur); cur = []
+    if cur:
+        groups.append(cur)
+    ev_g0 = [torch.cuda.Event(enable_timing=True) for _ in groups]
+    ev_g1 = [torch.cuda.Event(enable_timing=True) for _ in groups]
+
+    def launch_all(where):
+        """one pass over the mixed batch: the region pre-pass group by group on the region stream(s), each example's walk on its
+        stream as soon as its group's regions are known"""
         ev_fork.record(main_s)
-        region_s.wait_event(ev_fork)
-        if args.region_launches == "one":
-            ev_rall0.record(region_s)
-            capi.region_scan(bytes_all, off_all, table, stream=region_s)
-            ev_rall1.record(region_s)
-        for ex in order:
-            a, b = seg(ex)
-            if args.region_launches != "one":
-                ev_r0[ex].record(region_s)
-                capi.region_scan(bytes_all, off_all[a:b + 1], table[a:b], stream=region_s)
-            ev_r1[ex].record(region_s)
-            st = where[ex]
-            st.wait_event(ev_r1[ex])
-            if args.exp != "region-only" or not walked[0]:
-                shards[ex]["img"].match_tensors_regions(bytes_all, off_all[a:b + 1], table[a:b], results[a:b], stream=st)
-            ev_done[ex].record(st)
-        for ex in order:
+        for rs in region_pool:
+            rs.wait_event(ev_fork)
+        for k, grp in enumerate(groups):
+            rs = region_pool[k % len(region_pool)]
+            a, b = seg(grp[0])[0], seg(grp[-1])[1]
+            ev_g0[k].record(rs)
+            capi.region_scan(bytes_all, off_all[a:b + 1], table[a:b], stream=rs)
+            ev_g1[k].record(rs)
+            for ex in grp:
+                a, b = seg(ex)
+                st = where[ex]
+                st.wait_event(ev_g1[k])
+                if args.exp != "region-only" or not walked[0]:
+                    shards[ex]["img"].match_tensors_regions(bytes_all, off_all[a:b + 1], table[a:b], results[a:b], stream=st)
+                ev_done[ex].record(st)
+        for ex in layout:
             main_s.wait_event(ev_done[ex])
         ev_join.record(main_s)
 
-    # set-up (untimed): one pass with every walk on one stream measures each example's walk time; a step then starts the
-    # costliest walks first (their regions are scanned first) and leaves the cheapest one for the end, where it runs alone
-    order = sorted(shards)
+    # set-up (untimed): one pass with every walk on one stream measures each example's walk time; the walks are then spread
+    # over the walk streams, each onto the least loaded one
     where = {ex: walk_pool[0] for ex in shards}
     walked = [False]
-    launch_all(order, where)
+    launch_all(where)
     torch.cuda.synchronize()
     walked[0] = True
     cost = {ex: shards[ex]["img"].last_kernel_ms(local) for ex in shards}
-    if args.order:
-        order = [int(x) for x in args.order.split(",")]
-    else:
-        order = sorted(shards, key=lambda e: -cost[e])
     load = [0.0] * len(walk_pool)
-    for ex in order:
+    for ex in layout:
         k = load.index(min(load))
         load[k] += cost[ex]
         where[ex] = walk_pool[k]
+    order = layout
 
     kernel_ms = {ex: [] for ex in shards}
-    region_ms = {ex: [] for ex in shards}
     span_ms, region_all_ms = [], []
     counts = [total_strings] * world
 
     def step(record):
-        launch_all(order, where)
+        launch_all(where)
         full = sharding.gather_results(results, counts, dist, rank, world, comm_device=comm_dev) if dist else None
         if dist is None:
             full = sharding.pack_bitmap(results)                 # the bitmap a gather would send
@@ -501,10 +513,7 @@ def main():
             span_ms.append(ev_fork.elapsed_time(ev_join))
             for ex, sh in shards.items():
                 kernel_ms[ex].append(sh["img"].last_kernel_ms(local))
-                if args.region_launches != "one":
-                    region_ms[ex].append(ev_r0[ex].elapsed_time(ev_r1[ex]))
-            if args.region_launches == "one":
-                region_all_ms.append(ev_rall0.elapsed_time(ev_rall1))
+            region_all_ms.append(sum(ev_g0[k].elapsed_time(ev_g1[k]) for k in range(len(groups))))
         return full
 
     def fence():
@@ -543,13 +552,12 @@ def main():
         alg = total_bytes + 9 * total_strings
         kern_s = float(np.mean(span_ms)) * 1e-3
         achieved = alg / kern_s / 1e9
-        reg_total_ms = float(np.mean(region_all_ms)) if region_all_ms else float(sum(np.mean(region_ms[ex]) for ex in shards))
+        reg_total_ms = float(np.mean(region_all_ms))
         walk_total_ms = float(sum(np.mean(kernel_ms[ex]) for ex in shards))
         per_ex = {}
         for ex, sh in shards.items():
             a, b = seg(ex)
             per_ex[str(ex)] = {"bytes": sh["nbytes"], "walk_ms": float(np.mean(kernel_ms[ex])),
-                               "region_ms": float(np.mean(region_ms[ex])) if region_ms[ex] else None,
                                "accepted": int((results[a:b] == 1).sum().item())}
         traffic = None
         try:
@@ -576,11 +584,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "region_scan_kernel (%s) + mfa_jit_kernel (10 launches on %d streams, costliest first); duration = fork-to-join span of a step" % (
-                             "1 launch" if args.region_launches == "one" else "10 launches, one per example, on one stream", len(walk_pool)),
+                             "%d launch(es) over groups of consecutive examples %s" % (len(groups), groups), len(walk_pool)),
                          "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s,
                          # the kernel that reads the bytes: its own launches, timed with HIP events on its stream
-                         "region_scan_kernel": {"launches_per_step": 1 if region_all_ms else len(shards), "ms_per_step": reg_total_ms,
-                                                "ms_per_launch": reg_total_ms / (1 if region_all_ms else len(shards)),
+                         "region_scan_kernel": {"launches_per_step": len(groups), "ms_per_step": reg_total_ms,
+                                                "ms_per_launch": reg_total_ms / len(groups),
                                                 "achieved": total_bytes / (reg_total_ms * 1e-3) / 1e9, "frac": total_bytes / (reg_total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "note": "runs beside the walk kernels of earlier examples"},
                          "mfa_jit_kernel": {"launches_per_step": len(shards), "ms_sum_per_step": walk_total_ms,

@@ -41,6 +41,8 @@ struct Input {
     // region table of this string (regions.hip), nullptr = none: the lane measures regions itself
     const uint64_t* rt;
     uint32_t rt_cnt;
+    uint64_t* rt_cache;     // this lane's column of the LDS copy of the header's neighbours (first MFA_RT_CACHED entries)
+    uint32_t rt_stride;     // words between consecutive entries of that column
 };
 
 __device__ __forceinline__ void input_reset(Input& in, uint64_t base, uint32_t len) {
@@ -49,25 +51,55 @@ __device__ __forceinline__ void input_reset(Input& in, uint64_t base, uint32_t l
     in.run_lo = in.run_hi = 0; in.run_ch = 0x100u;
     in.per_lo = in.per_hi = 0; in.per_q = 0; in.dual_p = 0;
     in.prev_lo = in.prev_hi = 0; in.prev_q = 0;
-    in.rt = nullptr; in.rt_cnt = 0;
+    in.rt = nullptr; in.rt_cnt = 0; in.rt_cache = nullptr; in.rt_stride = 0;
 }
 
 // ---- region table (regions.hip; layout in include/mfa_hip.h) -------------------------------------------
 #define MFA_RT_WORDS 16u
 #define MFA_RT_OVERFLOW 0x100ull
 
-// attach the table of string `sid`.  Every entry is a true region; when the string had more regions than fit (overflow flag)
+#define MFA_RT_CACHED 2u          /* entries kept in LDS beside the header */
+// Attach the table of string `sid`.  Every entry is a true region; when the string had more regions than fit (overflow flag)
 // the table holds the longest ones, which only means that the lane walks through the others step by step.
-__device__ __forceinline__ void rt_attach(Input& in, const uint64_t* regions, uint64_t sid) {
+// The header and the first MFA_RT_CACHED entries (all there are, for most strings) are copied to this lane's column of
+// `cache` (LDS, [word][column]) with two 16-byte loads that go out together with the loads of the string's offsets; while
+// they are at hand the lane also touches the input around both ends of those regions and at both ends of the string:
+// that is where it will need bytes next (a jump ends near the end of its region), and a touched line is an L2 hit then
+// instead of a trip to HBM through a cold TLB.  Touched words are only xor-ed into `warm`, which nothing depends on.
+// rt_fetch issues the two loads (call it before anything waits for the string's offsets), rt_attach uses them.
+__device__ __forceinline__ void rt_fetch(const uint64_t* regions, uint64_t sid, uint4& a, uint4& b) {
+    a = b = make_uint4(0, 0, 0, 0);
     if (regions == nullptr) return;
     const uint64_t* t = regions + sid * MFA_RT_WORDS;
-    in.rt = t; in.rt_cnt = (uint32_t)t[0] & 0xffu;
+    a = *reinterpret_cast<const uint4*>(t); b = *reinterpret_cast<const uint4*>(t + 2);
+}
+__device__ __forceinline__ void rt_attach(Input& in, const uint64_t* regions, uint64_t sid, uint64_t* cache, uint32_t stride, uint32_t& warm,
+                                          const uint4 a, const uint4 b) {
+    if (regions == nullptr) return;
+    const uint64_t* t = regions + sid * MFA_RT_WORDS;
+    in.rt = t; in.rt_cnt = a.x & 0xffu; in.rt_cache = cache; in.rt_stride = stride;
+    const uint64_t e0 = ((uint64_t)a.w << 32) | a.z, e1 = ((uint64_t)b.y << 32) | b.x;
+    cache[0] = e0; cache[stride] = e1;
+    const uint64_t lim = in.total16 - 4u;
+    auto touch = [&](uint64_t off) {
+        off = off < lim ? off : lim;
+        warm ^= *reinterpret_cast<const uint32_t*>(in.bytes + (off & ~(uint64_t)3));
+    };
+    if (in.len > 64u) touch(in.base + in.len - 4u);
+    const uint64_t es[MFA_RT_CACHED] = {e0, e1};
+#pragma unroll
+    for (uint32_t k = 0; k < MFA_RT_CACHED; k++)
+        if (k < in.rt_cnt) {
+            const uint32_t mlo = (uint32_t)es[k] & 0x00ffffffu, mhi = (uint32_t)(es[k] >> 24) & 0x00ffffffu;
+            touch(in.base + mhi); touch(in.base + (mhi >= 32u ? mhi - 32u : 0u));
+            touch(in.base + mlo); touch(in.base + mlo + 32u);
+        }
 }
 
 // entry e in scan coordinates: scan[j] == scan[j + q] for lo <= j < hi - q
 template <bool REV>
 __device__ __forceinline__ void rt_entry(const Input& in, uint32_t e, uint32_t& lo, uint32_t& hi, uint32_t& q) {
-    const uint64_t w = in.rt[1u + e];
+    const uint64_t w = e < MFA_RT_CACHED ? in.rt_cache[e * in.rt_stride] : in.rt[1u + e];
     const uint32_t mlo = (uint32_t)w & 0x00ffffffu, mhi = (uint32_t)(w >> 24) & 0x00ffffffu;
     q = (uint32_t)(w >> 48) & 15u;
     lo = REV ? in.len - mhi : mlo;
@@ -237,6 +269,25 @@ __device__ __forceinline__ uint32_t run_end_from(const Input& in, uint32_t i, ui
     const int64_t lo = (int64_t)in.base, hi = (int64_t)(in.base + in.len - 2u - i);
     const int64_t q = last_not_equal(in.bytes, lo, hi, c);
     return q < lo ? in.len : (uint32_t)((int64_t)in.len - 1 - (q - lo));
+}
+
+// The same, looking at no more than `limit` positions: false = the run goes on beyond them (the caller then measures it with
+// the whole wave).  Runs the region table does not hold are short, so the lanes of a wave that need one measure theirs side
+// by side instead of queueing for the wave-wide scan.
+template <bool REV>
+__device__ __forceinline__ bool run_end_bounded(const Input& in, uint32_t i, uint32_t c, uint32_t limit, uint32_t& end) {
+    if (i + 1u >= in.len) { end = in.len; return true; }
+    if (!REV) {
+        const uint64_t p = in.base + i + 1u, e = in.base + in.len, e2 = e - p > limit ? p + limit : e;
+        const uint64_t q = first_not_equal(in.bytes, p, e2, c);
+        if (q < e2 || e2 == e) { end = (uint32_t)(q - in.base); return true; }
+        return false;
+    }
+    const int64_t lo = (int64_t)in.base, hi = (int64_t)(in.base + in.len - 2u - i), lo2 = hi - lo >= (int64_t)limit ? hi - (int64_t)limit + 1 : lo;
+    const int64_t q = last_not_equal(in.bytes, lo2, hi, c);
+    if (q >= lo2) { end = (uint32_t)((int64_t)in.len - 1 - (q - lo)); return true; }
+    if (lo2 == lo) { end = in.len; return true; }
+    return false;
 }
 
 // equality of scan[a, a+l) and scan[b, b+l): the two sides of a cell read (mfa.cpp:179-191)

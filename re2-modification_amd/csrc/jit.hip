@@ -198,8 +198,8 @@ void jit_print_stats(LaunchCtx& cx, const char* tag) {
     fprintf(stderr, "mfa_hip stats %s: wave-iterations %llu (dual %llu), lane-steps skipped %llu, probes %llu (hits %llu), scans %llu\n", tag,
             h[1], h[2], h[3], h[4], h[5], h[6]);
     fprintf(stderr, "mfa_hip stats %s: failed probes -- never settled %llu, dual period %llu, out of periodic input %llu\n", tag, h[11], h[12], h[13]);
-    if (h[10]) fprintf(stderr, "mfa_hip stats %s: share of wave time -- period scans %.1f%%, plain steps %.1f%%, dual steps %.1f%% (steps include cell-read scans)\n", tag,
-                      100.0 * h[7] / h[10], 100.0 * h[8] / h[10], 100.0 * h[9] / h[10]);
+    if (h[10]) fprintf(stderr, "mfa_hip stats %s: share of wave time -- tickets + string start %.1f%%, input byte %.1f%%, region look-up %.1f%%, period scans %.1f%%, plain steps %.1f%%, dual steps %.1f%% (steps include cell-read scans); %.1f M wave-cycles in all\n", tag,
+                      100.0 * h[14] / h[10], 100.0 * h[15] / h[10], 100.0 * h[16] / h[10], 100.0 * h[7] / h[10], 100.0 * h[8] / h[10], 100.0 * h[9] / h[10], h[10] / 1e6);
 }
 
 void jit_unload(DeviceState& ds) {

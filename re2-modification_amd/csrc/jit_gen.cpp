@@ -186,7 +186,7 @@ struct Gen {
                 o << ind << "      bool nr = " << rd << " && uni_needs_run(in, val(i), ch, val(" << vl << "), " << vf << ");\n";
                 o << ind << "      if (nr && in.rt != nullptr) {                      // the pre-pass knows every long run\n"
                   << ind << "        uint32_t rh;\n"
-                  << ind << "        if (rt_run<REV>(in, val(i), rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }\n"
+                  << ind << "        if (rt_run<REV>(in, val(i), rh) || run_end_bounded<REV>(in, val(i), ch, 192u, rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }\n"
                   << ind << "      }\n";
                 o << ind << "      for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {\n";
                 o << ind << "        const int L = __builtin_ctzll(sb);\n";
@@ -473,7 +473,7 @@ struct Gen {
         // the counters cost a dozen VGPRs: they exist only in objects compiled with -DMFA_STATS_BUILD=1 (MFA_STATS=1)
         o << "  unsigned long long* const stats = MFA_STATS_BUILD ? stats_arg : nullptr;\n";
         o << "  unsigned long long st_iter = 0, st_dual = 0, st_skip = 0, st_probe = 0, st_hit = 0, st_scan = 0; uint32_t st_steps = 0;\n";
-        o << "  unsigned long long tm_scan = 0, tm_plain = 0, tm_dual = 0, tm_total = stats ? clock64() : 0;\n";
+        o << "  unsigned long long tm_scan = 0, tm_plain = 0, tm_dual = 0, tm_ticket = 0, tm_byte = 0, tm_look = 0, tm_total = stats ? clock64() : 0;\n";
         o << "  const uint32_t lane = threadIdx.x & 63u;\n";
         o << "  const uint32_t col = lane < LANES ? lane : LANES;     // column of this lane in the LDS images (idle lanes share one)\n";
         o << "#if HUGE\n  uint32_t* const cur_mem = huge_lds + col;\n"
@@ -527,25 +527,35 @@ struct Gen {
              "  bool stable = false;     // the last two plain periods moved the slots by the same amounts\n"
              "  bool patient = false;    // a dual period right after the first plain one has failed on this string: wait for two equal movements\n"
              "  unsigned long long st_f_unst = 0, st_f_dual = 0, st_f_room = 0;\n";
+        o << "  __shared__ uint64_t rt_cache[MFA_RT_CACHED * (HUGE ? LANES + 1u : 64u)];      // first entries of every lane's region table\n"
+             "  bool first_round = true;\n  uint32_t warm = 0;\n";
         o << "  SlotSet<uint32_t> c(cur_mem);\n";
         for (const auto& w : words) o << "  c." << w << " = " << (w[0] == 'P' ? "MFA_EMPTY" : "0u") << ";\n";
-        o << "  for (;;) {\n";
+        o << "  for (;;) {\n    const unsigned long long tmA = stats ? clock64() : 0;\n";
         o << "    {\n      // hand strings to idle lanes: one atomic per wave, tickets dealt by lane rank\n"
              "      const bool want = !active && !exhausted && lane < LANES;\n      const unsigned long long wb = __ballot(want);\n"
              "      if (wb) {\n        unsigned long long first = 0;\n"
-             "        if (lane == (uint32_t)__builtin_ctzll(wb)) first = atomicAdd(counter, (unsigned long long)__builtin_popcountll(wb));\n"
-             "        first = ((unsigned long long)__shfl((uint32_t)(first >> 32), __builtin_ctzll(wb)) << 32) | __shfl((uint32_t)first, __builtin_ctzll(wb));\n"
+             "        if (first_round) first = (unsigned long long)blockIdx.x * LANES;      // the first strings of a wave need no ticket\n"
+             "        else {\n"
+             "          if (lane == (uint32_t)__builtin_ctzll(wb)) first = atomicAdd(counter, (unsigned long long)__builtin_popcountll(wb));\n"
+             "          first = ((unsigned long long)__shfl((uint32_t)(first >> 32), __builtin_ctzll(wb)) << 32) | __shfl((uint32_t)first, __builtin_ctzll(wb));\n"
+             "          first += (unsigned long long)gridDim.x * LANES;\n"
+             "        }\n"
+             "        first_round = false;\n"
              "        if (want) {\n          sid = first + (unsigned long long)__builtin_popcountll(wb & ((1ull << lane) - 1ull));\n"
-             "          if (sid >= n) exhausted = true;\n          else {\n            const uint64_t b = offsets[sid], e = offsets[sid + 1];\n"
+             "          if (sid >= n) exhausted = true;\n          else {\n            uint4 rta, rtb;\n            rt_fetch(regions, sid, rta, rtb);      // the table row and the offsets travel together\n            const uint64_t b = offsets[sid], e = offsets[sid + 1];\n"
              "            if (e - b > MFA_DEV_MAX_LEN) results[sid] = 2;\n            else {\n"
-             "              len = (uint32_t)(e - b); input_reset(in, b, len); rt_attach(in, regions, sid);\n"
+             "              len = (uint32_t)(e - b); input_reset(in, b, len); rt_attach(in, regions, sid, rt_cache + col, HUGE ? LANES + 1u : 64u, warm, rta, rtb);\n"
              "              i = 0; accept = false; active = true; phase = 0; probe_at = 0; backoff = 8; pp = 1; fails = 0; mult = 1; nper = 0; stable = false; patient = false;\n";
         for (const auto& w : words)
             o << "              c." << w << " = " << (w == "P" + num(g.h.start) ? "0u" : (w[0] == 'P' ? "MFA_EMPTY" : "0u")) << ";\n";
         o << "            }\n          }\n        }\n      }\n    }\n    if (!__any(active)) break;\n    st_iter++;\n";
         o << "    const uint32_t tr_i = i, tr_phase = phase, tr_pp = pp, tr_nper = nper; const bool tr_active = active;   // MFA_STATS builds: trace of the first strings\n";
         o << "    const bool final_pass = (i == len);\n    uint32_t ch = 0x100u;\n"
-             "    if (active && !final_pass) ch = stream_byte<REV>(in, i);\n";
+             "    const unsigned long long tmB = stats ? clock64() : 0;\n"
+             "    if (active && !final_pass) ch = stream_byte<REV>(in, i);\n"
+             "    if (stats) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); tm_byte += clock64() - tmB; }\n"
+             "    const unsigned long long tmC = stats ? clock64() : 0;\n";
         // decide whether this lane starts a probe: it must sit in a long run of equal bytes
         o << "    // does this lane sit at the start of a block that looks periodic?  then find how far the periodic region goes\n"
              "    uint32_t q = 0u;\n"
@@ -568,6 +578,7 @@ struct Gen {
              "        } else probe_at = rn;                       // look again where the next region starts (never, if there is none)\n"
              "      } else probe_at = ~0u;                        // no table: every step is executed\n"
              "    }\n"
+             "    if (stats) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); tm_look += clock64() - tmC; }\n"
              "    const unsigned long long tm0 = stats ? clock64() : 0;\n"
              "#if MFA_INLINE_SCAN\n"
              "    bool need_scan = q != 0u && !(in.per_q == q && in.per_lo <= i && i < in.per_hi);\n"
@@ -669,13 +680,14 @@ struct Gen {
              "      tr[0] = tr_i; tr[1] = tr_phase | (q << 4) | (tr_pp << 8) | (tr_nper << 16) | ((uint32_t)__any(tr_phase == 2u) << 24) | 0x80000000u;\n"
              "    }\n";
         o << "    if (active) {\n      const bool done = accept || final_pass || !any_next;\n      i++;\n"
-             "      st_steps++;\n      if (done) { results[sid] = accept ? 1 : 0; active = false; phase = 0u;\n"
+             "      st_steps++;\n      if (done) { results[sid] = (warm == 0x9e3779b9u && len == 0xffffffffu) ? 3 : (accept ? 1 : 0); active = false; phase = 0u;\n"
              "        if (stats && sid < (1u << 20)) ((uint32_t*)(stats + 16))[sid] = st_steps;\n        st_steps = 0;\n";
         for (const auto& w : words)
             if (w[0] == 'P') o << "        c." << w << " = MFA_EMPTY;\n";
         o << "      }\n    }\n  }\n";
         o << "  if (stats) {\n    if (lane == 0) { atomicAdd(&stats[0], st_iter); atomicAdd(&stats[1], st_dual); atomicAdd(&stats[6], tm_scan); atomicAdd(&stats[7], tm_plain);\n"
-             "      atomicAdd(&stats[8], tm_dual); atomicAdd(&stats[9], (unsigned long long)clock64() - tm_total); }\n"
+             "      atomicAdd(&stats[8], tm_dual); atomicAdd(&stats[9], (unsigned long long)clock64() - tm_total);\n"
+             "      atomicAdd(&stats[13], tm_ticket); atomicAdd(&stats[14], tm_byte); atomicAdd(&stats[15], tm_look); }\n"
              "    if (lane < LANES) {                             // lanes that never carry a string hold no meaningful counts\n"
              "      atomicAdd(&stats[2], st_skip); atomicAdd(&stats[3], st_probe); atomicAdd(&stats[4], st_hit); atomicAdd(&stats[5], st_scan);\n"
              "      atomicAdd(&stats[10], st_f_unst); atomicAdd(&stats[11], st_f_dual); atomicAdd(&stats[12], st_f_room);\n    }\n  }\n}\n";

@@ -96,14 +96,22 @@ __device__ __forceinline__ uint32_t block_mask(uint32_t w0, uint32_t w1, uint32_
 
 struct RegionState {
     int32_t  last_dirty[9];      // per period: the last dirty block seen (scalar registers after unrolling)
+    int32_t  cand_x[9], cand_y[9];   // per period: the candidate recorded last
     uint32_t ncand;              // candidates recorded so far (wave-uniform)
     // candidate e lives in lane e
     uint32_t cq;
     int32_t  cx, cy;
 };
 
-__device__ __forceinline__ void emit(RegionState& st, uint32_t lane, uint32_t q, int32_t x, int32_t y) {
-    if (lane == st.ncand) { st.cq = q; st.cx = x; st.cy = y; }
+// A candidate of period Q that a candidate of a proper divisor of Q covers (to within a block at either end) is not recorded:
+// the divisor's region says more.  Divisors are handled before Q in every row, so their candidates for the same stretch exist.
+template <int Q>
+__device__ __forceinline__ void emit(RegionState& st, uint32_t lane, int32_t x, int32_t y) {
+    st.cand_x[Q] = x; st.cand_y[Q] = y;
+#pragma unroll
+    for (int d = 1; d <= 4; d++)
+        if (d < Q && Q % d == 0 && st.cand_x[d] <= x + 1 && st.cand_y[d] >= y - 1) return;
+    if (lane == st.ncand) { st.cq = Q; st.cx = x; st.cy = y; }
     st.ncand++;
 }
 
@@ -114,7 +122,7 @@ __device__ __forceinline__ void book(RegionState& st, uint32_t lane, unsigned lo
     if (dirty == ~0ull && last == base - 1) { last = base + 63; return; }      // nothing clean anywhere: the common dirty case
     if (dirty == 0ull) return;
     const int32_t first = (int32_t)__builtin_ctzll(dirty), top = 63 - (int32_t)__builtin_clzll(dirty);
-    if (base + first - last - 1 >= kCleanMin) emit(st, lane, Q, last, base + first);
+    if (base + first - last - 1 >= kCleanMin) emit<Q>(st, lane, last, base + first);
     // clean stretches between dirty blocks of this row
     unsigned long long z = ~dirty;
     unsigned long long zz = z;
@@ -125,7 +133,7 @@ __device__ __forceinline__ void book(RegionState& st, uint32_t lane, unsigned lo
         int32_t prev = first;
         for (unsigned long long m = dirty & (dirty - 1ull); m; m &= m - 1ull) {
             const int32_t nxt = (int32_t)__builtin_ctzll(m);
-            if (nxt - prev - 1 >= kCleanMin) emit(st, lane, Q, base + prev, base + nxt);
+            if (nxt - prev - 1 >= kCleanMin) emit<Q>(st, lane, base + prev, base + nxt);
             prev = nxt;
         }
     }
@@ -138,9 +146,13 @@ __device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, uint3
     book<Q>(st, lane, __ballot((mask & qbit(Q)) != 0u), base);
 }
 
-template <int MODE>
-__global__ void __launch_bounds__(256) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
+// MODE 1: streaming phase only (development).  PF: rows whose loads are in flight beyond the one being looked at.
+// DPP: the 8 bytes behind a block come from the neighbouring lane's registers (lane 63: from the next row's lane 0) instead
+// of a second load.
+template <int MODE, int PF, bool DPP, int GRP>
+__global__ void __launch_bounds__(256, (GRP >= 8 ? 4 : GRP >= 4 ? 6 : 8)) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
                                                           uint64_t* __restrict__ table) {
+    constexpr int NB = PF + 1;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4u;
     const uint64_t total16 = (offsets[n] + 15u) & ~(uint64_t)15;        // the batch is readable below this offset
@@ -153,36 +165,56 @@ __global__ void __launch_bounds__(256) region_scan_kernel(const uint8_t* __restr
         const uint32_t off0 = (uint32_t)(b - a0);
         const int32_t nblk = (int32_t)((off0 + len + 15u) >> 4);
         const int32_t endblk = len >= 8u ? (int32_t)((off0 + len - 8u) >> 4) : 0;
+        const int32_t nrows = (nblk + 63) >> 6;
         RegionState st;
 #pragma unroll
-        for (int q = 0; q < 9; q++) st.last_dirty[q] = -1;
+        for (int q = 0; q < 9; q++) { st.last_dirty[q] = -1; st.cand_x[q] = 0x7fffffff; st.cand_y[q] = -1; }
         st.ncand = 0; st.cq = 0; st.cx = 0; st.cy = 0;
         // Rows whose blocks all carry the same mask as the row before (a stretch inside one periodic region, or text in which
         // every block is dirty for every period) need no book-keeping at all: one compare and one ballot.  `settled` is that
         // mask (~0u: the last row was not uniform); the dirty periods' last_dirty is caught up when the stretch ends.
-        uint32_t settled = ~0u;
-        // no branch around the loads (the compiler then counts them and waits for the older pair only): rows are read whole,
+        uint32_t settled = ~0u, vp = 0u;
+        // no branch around the loads (the compiler then counts them and waits for the oldest only): rows are read whole,
         // lanes past the last block re-read it, and the 8 bytes behind the very last block of the batch come from inside it;
         // what such lanes load is never looked at (their blocks are forced)
         const uint64_t ymax = total16 - 8u;
         auto load_row = [&](int32_t row, uint4& x, uint2& y) {
+            row = row < nrows ? row : nrows - 1;
             int32_t blk = row * 64 + (int32_t)lane;
             blk = blk < nblk ? blk : nblk - 1;
             const uint64_t addr = a0 + 16u * (uint64_t)blk;
-            const uint64_t ya = addr + 16u <= ymax ? addr + 16u : ymax;
             x = *reinterpret_cast<const uint4*>(bytes + addr);
-            y = *reinterpret_cast<const uint2*>(bytes + ya);
+            if (!DPP) {
+                const uint64_t ya = addr + 16u <= ymax ? addr + 16u : ymax;
+                y = *reinterpret_cast<const uint2*>(bytes + ya);
+            }
         };
-        uint4 x, nx;
-        uint2 y, ny;
-        load_row(0, x, y);
-        for (int32_t row = 0; row * 64 < nblk; row++) {
-            load_row((row + 1) * 64 < nblk ? row + 1 : row, nx, ny);       // the next row is on its way while this one is looked at
-            const int32_t base = row * 64, blk = base + (int32_t)lane;
+        // one row: x = this lane's block, y = the 8 bytes behind it
+        auto process = [&](const int32_t row, const uint4 x, const uint2 y) {
+    const int32_t base = row * 64, blk = base + (int32_t)lane;
             const bool forced = blk == 0 || blk >= endblk;
+            // Inside a stretch with a clean period (vp = the smallest one) a row looks like the one before as soon as the 24
+            // bytes every lane holds are vp-periodic: the stretch then continues with the same word, and whether a block is
+            // dirty for a period depends on that word only.
+            if (vp != 0u) {
+                uint32_t s0, s1, s2, s3;
+                if (vp < 4u) {
+                    s0 = __builtin_amdgcn_alignbyte(x.y, x.x, vp); s1 = __builtin_amdgcn_alignbyte(x.z, x.y, vp);
+                    s2 = __builtin_amdgcn_alignbyte(x.w, x.z, vp); s3 = __builtin_amdgcn_alignbyte(y.x, x.w, vp);
+                } else if (vp < 8u) {
+                    s0 = __builtin_amdgcn_alignbyte(x.z, x.y, vp - 4u); s1 = __builtin_amdgcn_alignbyte(x.w, x.z, vp - 4u);
+                    s2 = __builtin_amdgcn_alignbyte(y.x, x.w, vp - 4u); s3 = __builtin_amdgcn_alignbyte(y.y, y.x, vp - 4u);
+                } else { s0 = x.z; s1 = x.w; s2 = y.x; s3 = y.y; }
+                uint32_t diff = (x.x ^ s0) | (x.y ^ s1) | (x.z ^ s2) | (x.w ^ s3);
+                if (vp < 8u) {                                 // bytes 16..23 among themselves
+                    const uint64_t yy = ((uint64_t)y.y << 32) | y.x;
+                    const uint64_t dd = (yy ^ (yy >> (8u * vp))) << (8u * vp);      // the low 8 - vp bytes of the difference
+                    diff |= (uint32_t)dd | (uint32_t)(dd >> 32);
+                }
+                if (!__any(forced || diff != 0u)) return;
+            }
             const uint32_t mask = forced ? kAllDirty : block_mask(x.x, x.y, x.z, x.w, y.x, y.y);
-            x = nx; y = ny;
-            if (__all(mask == settled)) continue;
+            if (__all(mask == settled)) return;
             const uint32_t was = settled != ~0u ? settled : 0u;
             row_period<1>(st, lane, mask, was, base);
             row_period<2>(st, lane, mask, was, base);
@@ -194,6 +226,81 @@ __global__ void __launch_bounds__(256) region_scan_kernel(const uint8_t* __restr
             row_period<8>(st, lane, mask, was, base);
             const uint32_t m0 = __builtin_amdgcn_readfirstlane(mask);
             settled = __all(mask == m0) ? m0 : ~0u;
+            vp = 0u;
+            if (settled != ~0u) {
+#pragma unroll
+                for (int q = 8; q >= 1; q--)
+                    if (!(settled & qbit(q))) vp = (uint32_t)q;
+            }
+        };
+        if (GRP == 0) {
+            uint4 xs[NB];
+            uint2 ys[NB];
+#pragma unroll
+            for (int k = 0; k < NB; k++) { xs[k] = make_uint4(0, 0, 0, 0); ys[k] = make_uint2(0, 0); }
+            if (nrows > 0) {
+#pragma unroll
+                for (int k = 0; k < PF; k++) load_row(k, xs[k], ys[k]);
+            }
+            for (int32_t row0 = 0; row0 < nrows; row0 += NB) {
+#pragma unroll
+                for (int k = 0; k < NB; k++) {
+                    const int32_t row = row0 + k;
+                    if (row >= nrows) break;
+                    load_row(row + PF, xs[(k + PF) % NB], ys[(k + PF) % NB]);      // rows ahead are on their way while this one is looked at
+                    const uint4 x = xs[k];
+                    uint2 y = ys[k];
+                    if (DPP) {                                           // lane L: the first 8 bytes of lane L + 1; lane 63: of the next row's lane 0
+                        const uint4 xn = xs[(k + 1) % NB];
+                        const uint32_t n0 = __builtin_amdgcn_readfirstlane(xn.x), n1 = __builtin_amdgcn_readfirstlane(xn.y);
+                        y.x = __builtin_amdgcn_update_dpp(n0, x.x, 0x130, 0xf, 0xf, false);      // wave_shl:1
+                        y.y = __builtin_amdgcn_update_dpp(n1, x.y, 0x130, 0xf, 0xf, false);
+                    }
+                    process(row, x, y);
+                }
+            }
+        } else {
+            // Bursts: the loads of GRP consecutive rows (GRP KiB of the string, contiguous) go out back to back -- DRAM pages and
+            // TLB entries are used whole -- while the burst before is looked at.  Two register buffers; the 8 bytes behind a burst
+            // (for lane 63 of its last row) come with it as one broadcast load.
+            constexpr int G = GRP > 0 ? GRP : 1;
+            const int32_t ngroups = (nrows + G - 1) / G;
+            auto load_group = [&](int32_t g, uint4 (&buf)[G], uint2& tail) {
+#pragma unroll
+                for (int k = 0; k < G; k++) {
+                    int32_t row = g * G + k;
+                    row = row < nrows ? row : nrows - 1;
+                    int32_t blk = row * 64 + (int32_t)lane;
+                    blk = blk < nblk ? blk : nblk - 1;
+                    buf[k] = *reinterpret_cast<const uint4*>(bytes + a0 + 16u * (uint64_t)blk);
+                }
+                uint64_t ta = a0 + 16u * 64u * (uint64_t)((g + 1) * G);
+                ta = ta <= ymax ? ta : ymax;
+                tail = *reinterpret_cast<const uint2*>(bytes + ta);
+            };
+            auto run_group = [&](int32_t g, const uint4 (&buf)[G], const uint2 tail) {
+#pragma unroll
+                for (int k = 0; k < G; k++) {
+                    const int32_t row = g * G + k;
+                    if (row >= nrows) break;
+                    const uint32_t n0 = __builtin_amdgcn_readfirstlane(k + 1 < G ? buf[(k + 1) % G].x : tail.x);
+                    const uint32_t n1 = __builtin_amdgcn_readfirstlane(k + 1 < G ? buf[(k + 1) % G].y : tail.y);
+                    uint2 y;
+                    y.x = __builtin_amdgcn_update_dpp(n0, buf[k].x, 0x130, 0xf, 0xf, false);          // wave_shl:1
+                    y.y = __builtin_amdgcn_update_dpp(n1, buf[k].y, 0x130, 0xf, 0xf, false);
+                    process(row, buf[k], y);
+                }
+            };
+            uint4 bufa[G], bufb[G];
+            uint2 ta = make_uint2(0, 0), tb = make_uint2(0, 0);
+            if (ngroups > 0) load_group(0, bufa, ta);
+            for (int32_t g = 0; g < ngroups; g += 2) {
+                load_group(g + 1 < ngroups ? g + 1 : g, bufb, tb);
+                run_group(g, bufa, ta);
+                if (g + 1 >= ngroups) break;
+                load_group(g + 2 < ngroups ? g + 2 : g + 1, bufa, ta);
+                run_group(g + 1, bufb, tb);
+            }
         }
         if (MODE == 1) { if (lane == 0) tab[0] = st.ncand; continue; }            // experiment: streaming phase only
         // ---- exact ends: lane c resolves candidate c against the real bytes
@@ -257,7 +364,16 @@ __global__ void __launch_bounds__(256) region_scan_kernel(const uint8_t* __restr
             keep = keep && longer < MFA_REGION_MAX;
             kb = __ballot(keep);
         }
-        const uint32_t rank = (uint32_t)__builtin_popcountll(kb & ((1ull << lane) - 1ull));
+        // entries go out in the order of their starts (the walk kernels copy the first few to LDS: the ones they meet first)
+        uint32_t rank = 0;
+        {
+            const uint32_t key = (lo << 4) | q;
+            for (unsigned long long m = kb; m; m &= m - 1ull) {
+                const int f = __builtin_ctzll(m);
+                const uint32_t kf = __shfl(key, f);
+                if (kf < key || (kf == key && (uint32_t)f < lane)) rank++;
+            }
+        }
         if (keep && rank < MFA_REGION_MAX) tab[1 + rank] = (uint64_t)lo | ((uint64_t)hi << 24) | ((uint64_t)q << 48);
         if (lane == 0) tab[0] = (uint64_t)(total < MFA_REGION_MAX ? total : MFA_REGION_MAX) |
                                 ((total > MFA_REGION_MAX || st.ncand > 64u) ? MFA_REGION_OVERFLOW : 0ull);
@@ -269,10 +385,21 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     uint64_t blocks = (n + 3) / 4;
     const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * 8u * 64u;      // beyond this waves take several strings each
     if (blocks > cap) blocks = cap;
-    const char* em = getenv("MFA_REGION_MODE");                   // development: 1 = streaming phase only
+    const char* em = getenv("MFA_REGION_MODE");                   // development knobs
+    const char* ep = getenv("MFA_REGION_PF");
+    const char* ed = getenv("MFA_REGION_DPP");
+    const int mode = em ? atoi(em) : 0, pf = ep ? atoi(ep) : 1, dpp = ed ? atoi(ed) : 0;
     if (const char* ec = getenv("MFA_REGION_CAP")) { const uint64_t c = (uint64_t)atoll(ec); if (c > 0 && blocks > c) blocks = c; }
-    if (em && atoi(em) == 1) hipLaunchKernelGGL((region_scan_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_bytes, d_offsets, n, d_table);
-    else hipLaunchKernelGGL((region_scan_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_bytes, d_offsets, n, d_table);
+    const char* eg = getenv("MFA_REGION_GRP");
+    const int grp = eg ? atoi(eg) : 0;
+#define GO(M, P, D, G) hipLaunchKernelGGL((region_scan_kernel<M, P, D, G>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_bytes, d_offsets, n, d_table)
+    if (mode == 1) { if (grp == 4) GO(1, 1, true, 4); else if (grp == 2) GO(1, 1, true, 2); else if (dpp) GO(1, 2, true, 0); else GO(1, 1, false, 0); }
+    else if (grp == 4) GO(0, 1, true, 4);
+    else if (grp == 2) GO(0, 1, true, 2);
+    else if (grp == 8) GO(0, 1, true, 8);
+    else if (dpp) GO(0, 2, true, 0);
+    else GO(0, 1, false, 0);
+#undef GO
     HIP_TRY(hipGetLastError());
     return MFA_OK;
 }
