@@ -132,7 +132,8 @@ def cpu_baseline(corpus, shards, gpu_results, budget_strings=8, cap=32768):
                 mism += sum(1 for a, b in zip(want, got) if a != b) + abs(len(want) - len(got))
                 jobs.append((blob_path, sample))
             # the restatement on every host core: the parity sample dealt round-robin to one process per core
-            cores = os.cpu_count() or 1
+            # this process's CPU share (the GPU box gives one GPU's share of the host, not all of its cores)
+            cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
             from concurrent.futures import ThreadPoolExecutor
             work = []
             for blob_path, sample in jobs:

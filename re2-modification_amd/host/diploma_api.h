@@ -28,9 +28,10 @@
 //  * match() does not walk the graph on the CPU.  The graph is frozen into an automaton
 //    image (include/mfa_image_format.h) and handed to libmfa_hip.so; there is no CPU fallback:
 //    without a usable GPU match() throws std::runtime_error.
-//  * The BNF rewriter (regex/bnf.cpp, helpers.cpp) and reversal of memory regexes
-//    (regex/reverse.cpp:59-113) are not part of this round; compile()
-//    with use_bnf / use_reverse on a regex with memory throws std::runtime_error saying so.
+//  * The BNF rewriter and the reversal of memory regexes (regex/bnf.cpp, helpers.cpp, reverse.cpp) are restated in
+//    bnf_rewrite.cpp.  Two paths of the reference's rewriter read freed or uninitialised memory (a default argument that
+//    is an iterator into a destroyed temporary, bnf.cpp:805 with 544-552; an uninitialised iterator, bnf.cpp:409-418):
+//    regexes that reach them throw std::runtime_error here instead of repeating an accident.
 #ifndef DIPLOMA_API_H
 #define DIPLOMA_API_H
 
@@ -191,8 +192,18 @@ public:
     bool is_one_unamb = false;
     bool is_bad_bnf = false;
 
-    set<string> maybe_initialized;    // cells some path may initialise
-    set<string> maybe_read;           // cells some path may read
+    bool is_slided = false;           // an iteration over a read/write block that has been unrolled already (regex.h:97)
+
+    // variable-flow sets (regex.h:99-121), maintained while a tree is analysed or rebuilt
+    map<string, list<Regexp*>> initialized;   // cells initialised on every path, with their initialisations in order
+    set<string> read;                         // cells read on every path
+    set<string> maybe_initialized;            // cells some path may initialise
+    set<string> maybe_read;                   // cells some path may read
+    set<string> uninited_read;                // reads some path reaches without an initialisation before them
+    set<string> unread_init;                  // initialisations some path leaves unread
+    set<string> definitely_unread_init;       // initialisations nothing behind them reads (cleared from the result)
+    set<string> definitely_uninit_read;       // reads no initialisation precedes (under an iteration)
+    set<string> rw_vars;                      // cells that form a read..write block at this level
 
     Regexp() = default;
     explicit Regexp(RegexpType t) : regexp_type(t) {}
@@ -201,8 +212,9 @@ public:
     string to_string();
     bool is_backref_correct();
     BinaryTree* to_binary_tree();
-    Regexp* reverse();                                // memory-less regexes only in this round
-    Regexp* bnf(bool is_log = false);                 // not in this round: throws
+    Regexp* reverse();                                // regex/reverse.cpp:104-113
+    Regexp* bnf(bool is_log = false);                 // regex/bnf.cpp:894-919
+    bool is_acreg();                                  // regex/helpers.cpp:4-21
     Automata* compile(bool& is_mfa, bool use_reverse, bool use_bnf, bool use_ssnf, bool use_log = false);
 
 private:
@@ -211,8 +223,50 @@ private:
     void wrap_kleene(char c);
     void close_backreference(string name);
     void close_enumeration();
-    void collect_memory_use();
     Regexp* mirrored();
+
+    // ---- bnf_rewrite.cpp: the reference's regex/helpers.cpp, regex/bnf.cpp, regex/reverse.cpp and the flow analysis of
+    //      regex/regex.cpp:91-147 restated (same order of every list and set operation, since the result is order sensitive)
+    void analyse(set<string>& seen_inits);
+    bool same_shape(Regexp* other);
+    Regexp* last_init(const string& var);
+    Regexp* prefix_last_init(const string& var, list<Regexp*>::iterator it);
+    bool crosses_references();
+    map<string, list<string>> reads_inside_inits();
+    void put(Regexp* r, bool front);
+    void put_sequence(Regexp* r, bool front);
+    void put_choice(Regexp* r, bool front);
+    void add(Regexp* r, bool front = false);
+    void flow_after(Regexp* r);                       // concat_vars
+    void flow_beside(Regexp* r);                      // alt_vars
+    void flow_under_star(Regexp* r);                  // star_kleene_vars
+    void flow_same(Regexp* r);                        // copy_vars
+    void flow_replace(Regexp* r);                     // change_vars
+    static Regexp* clone(Regexp* r);                  // copy
+    Regexp* unwrap_single();                          // simplify_conc_alt
+    set<string> choice_free_reads();
+    map<string, int> choice_init_counts();
+    Regexp* strip_dead_memory(set<string> init_vars, set<string> read_vars);
+    Regexp* unroll_plus(set<string> vars, bool strip = true);
+    Regexp* unroll(set<string> vars, bool strip = true);
+    Regexp* unroll_for_reads(set<string> vars, Regexp* parent, list<Regexp*>::iterator where);
+    list<string> order_choice_vars(bool smallest_first);
+    Regexp* split_choice_under_star(bool smallest_first = false);
+    Regexp* split_choice_on(const string& var);
+    Regexp* denest(Regexp* a_alt, Regexp* b_alt);
+    Regexp* slide_last_init(set<string> vars);
+    Regexp* rw_sequence_under_star(Regexp* parent, bool have_where, list<Regexp*>::iterator where);
+    Regexp* rw_choice_under_star();
+    Regexp* rw_under_star(Regexp* parent, bool have_where, list<Regexp*>::iterator where);
+    Regexp* hoist_choice_out_of_init();
+    Regexp* spread_right(int alt_pos);
+    Regexp* spread_left(int alt_pos);
+    Regexp* spread_both(int alt_pos);
+    Regexp* sequence_fix_unread_inits();
+    Regexp* sequence_fix_free_reads();
+    Regexp* normalise(Regexp* parent, bool under_star, bool have_where, list<Regexp*>::iterator where);
+    Regexp* swap_reads_and_inits(set<Regexp*>& done);
+    void bind_reads(map<string, Regexp*>& init);
 };
 
 // ---- bt/binary_tree.h ---------------------------------------------------------------------------------

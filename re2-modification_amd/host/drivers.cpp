@@ -104,16 +104,17 @@ void match_mfa(string regexp_str, const string& input_path) {
 }
 
 // ---- `./diploma -match N` ------------------------------------------------------------------------------
-// The reference's experiment (matchers/example_runner.cpp): the regex of test/example_N/regexp.txt (line 1) against
-// prefix + pumped_string(pump_size) + suffix for growing pump sizes, one "len seconds" line per string in
-// test/example_N/diploma_results.txt, until a match takes >= 0.5 s.  Kept from the reference: the files and their
-// format, the pump-size schedule (500, doubling every round and once more every tenth round), the prefix that
-// accumulates the previous string (example_runner.cpp:123 appends in place), the 0.5 s stop rule.  Different: the
-// time is wall time of one GPU match of one string (copy in, launch, copy out) instead of clock() around the CPU
-// loop; a running match is not interrupted, the series ends after the first slow one; strings beyond the device
-// limit (16 MiB) end the series; the `-bnf` / `-reverse` curves (diploma_bnf_results.txt, diploma_reverse_results.txt)
-// need regex/bnf.cpp and are not written -- the round counter that drives the extra doubling advances as if the
-// reversed automaton were still running, which is what happens in the reference until it times out.
+// The reference's experiment (matchers/example_runner.cpp:84-151): the regex of test/example_N/regexp.txt (line 1), compiled
+// three ways -- plain, `-bnf`, `-reverse` (all with ssnf, which is a no-op on these paths) -- against
+// prefix + pumped_string(pump_size) + suffix for growing pump sizes; one "len seconds" line per string and automaton in
+// test/example_N/diploma_results.txt, diploma_bnf_results.txt, diploma_reverse_results.txt, each series until a match takes
+// >= 0.5 s.  Kept from the reference: the files and their format, the three compile() calls on the one parsed tree in the
+// reference's order (they share nodes, so the order is part of the result), the pump-size schedule (500, doubling every
+// round and once more whenever the count of rounds the reversed automaton has run is a multiple of ten -- which is every
+// round once it has stopped at such a count), the prefix that accumulates the previous string (example_runner.cpp:123
+// appends in place), the 0.5 s stop rule.  Different: the time is wall time of one GPU match of one string (copy in, launch,
+// copy out) instead of clock() around the CPU loop; a running match is not interrupted, a series ends after its first slow
+// one; strings beyond the device limit (16 MiB) end all series.
 // DIPLOMA_FRESH_PREFIX=1 uses the file's prefix for every string (matcher.py:58), which is what bench.py measures.
 std::string pumped_string(int n, vector<string> pump_v) {
     const int parts = (int)pump_v.size() / 2 + 1, joints = (int)pump_v.size() - parts;
@@ -143,28 +144,41 @@ void run_configuration_examples(const string& number) {
     }
     cout << regexp_str << endl;
     Regexp* regexp = Regexp::parse_regexp(regexp_str);
+    regexp->is_backref_correct();                                       // example_runner.cpp:107 (compile() analyses again, like there)
     bool is_mfa = true;
-    Automata* automata = regexp->compile(is_mfa, false, false, true, false);
-    MFA* mfa = is_mfa ? static_cast<MFA*>(automata) : nullptr;
-    std::cerr << "diploma: -bnf / -reverse curves are not written in this build (regex/bnf.cpp not restated)\n";
-    std::ofstream result_file(dir + "diploma_results.txt", std::ofstream::out | std::ofstream::trunc);
+    struct Series { Automata* automata; bool is_mfa; bool stopped; std::ofstream file; };
+    Series series[3];
+    const char* names[3] = {"diploma_results.txt", "diploma_bnf_results.txt", "diploma_reverse_results.txt"};
+    const bool rev[3] = {false, false, true}, bnf[3] = {false, true, true};
+    for (int k = 0; k < 3; k++) {
+        series[k].automata = regexp->compile(is_mfa, rev[k], bnf[k], true, false);
+        series[k].is_mfa = is_mfa;
+        series[k].stopped = false;
+        series[k].file.open(dir + names[k], std::ofstream::out | std::ofstream::trunc);
+    }
     const char* fresh_env = std::getenv("DIPLOMA_FRESH_PREFIX");
     const bool fresh = fresh_env && fresh_env[0] == '1';
     const size_t len_limit = size_t(INT32_MAX / 10), device_limit = 0x00ffffffu;
     long long pump_size = 500;
-    int round = 0;
+    int count = 0;
     string grown = prefix;
-    for (size_t len = prefix.size() + (size_t)pump_size + suffix.size(); len < len_limit;) {
+    size_t len = prefix.size() + (size_t)pump_size + suffix.size();
+    while (!(series[0].stopped && series[1].stopped && series[2].stopped) && len < len_limit) {
         const string input = (fresh ? prefix : grown) + pumped_string((int)pump_size, pump) + suffix;
         grown = input;
         len = input.size();
         pump_size += pump_size;
         if (len > device_limit) break;
-        const auto t0 = std::chrono::steady_clock::now();
-        if (mfa) mfa->match(input); else automata->match(input);
-        const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-        if (seconds < 1) result_file << len << " " << seconds << endl;
-        if (seconds >= 0.5) break;
-        if (++round % 10 == 0) pump_size *= 2;
+        for (int k = 0; k < 3; k++) {
+            Series& s = series[k];
+            if (s.stopped) continue;
+            const auto t0 = std::chrono::steady_clock::now();
+            if (s.is_mfa) static_cast<MFA*>(s.automata)->match(input); else s.automata->match(input);
+            const double seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (seconds >= 0.5) s.stopped = true;
+            if (seconds < 1) s.file << len << " " << seconds << endl;
+            if (k == 2) count++;
+        }
+        if (count % 10 == 0) pump_size *= 2;
     }
 }

@@ -242,33 +242,6 @@ string Regexp::to_string() {                                                    
     }
 }
 
-// Which cells the regex may initialise / read.  The reference computes a dozen flow sets
-// (regex.cpp:91-147, helpers.cpp:118-212); compile() only looks at whether these two are empty
-// (regex.cpp:271), and both propagate upward by plain union on every node kind.
-void Regexp::collect_memory_use() {
-    maybe_initialized.clear();
-    maybe_read.clear();
-    auto absorb = [&](Regexp* r) {
-        r->collect_memory_use();
-        maybe_initialized.insert(r->maybe_initialized.begin(), r->maybe_initialized.end());
-        maybe_read.insert(r->maybe_read.begin(), r->maybe_read.end());
-    };
-    switch (regexp_type) {
-        case reference: maybe_read.insert(variable); break;
-        case alternationExpr: case concatenationExpr:
-            for (Regexp* r : sub_regexps) absorb(r);
-            break;
-        case kleeneStar: case kleenePlus: absorb(sub_regexp); break;
-        case backreferenceExpr: absorb(sub_regexp); maybe_initialized.insert(variable); break;
-        default: break;
-    }
-}
-
-bool Regexp::is_backref_correct() {            // regex.cpp:209-221 (its verdict is unused on the match path)
-    collect_memory_use();
-    return true;
-}
-
 BinaryTree* Regexp::to_binary_tree() {                                           // regex.cpp:223-264
     BinaryTree* t = new BinaryTree(regexp_type);
     switch (regexp_type) {
@@ -296,39 +269,7 @@ BinaryTree* Regexp::to_binary_tree() {                                          
     return t;
 }
 
-Regexp* Regexp::mirrored() {                                                     // reverse.cpp:30-57
-    switch (regexp_type) {
-        case kleeneStar: case kleenePlus: {
-            Regexp* r = new Regexp(regexp_type);
-            r->sub_regexp = sub_regexp->mirrored();
-            return r;
-        }
-        case concatenationExpr: case alternationExpr: {
-            Regexp* r = new Regexp(regexp_type);
-            for (Regexp* s : sub_regexps) {
-                if (regexp_type == concatenationExpr) r->sub_regexps.push_front(s->mirrored());
-                else r->sub_regexps.push_back(s->mirrored());
-            }
-            return r;
-        }
-        default: return this;
-    }
-}
-
-Regexp* Regexp::reverse() {                                                      // reverse.cpp:104-113
-    collect_memory_use();
-    if (!maybe_initialized.empty() || !maybe_read.empty())
-        throw std::runtime_error("Regexp::reverse: reversing a regex with memory cells needs the BNF rewriter "
-                                 "(regex/bnf.cpp, regex/reverse.cpp:59-102), which this build does not include yet");
-    return mirrored();
-}
-
-Regexp* Regexp::bnf(bool) {
-    throw std::runtime_error("Regexp::bnf: the backreference-normal-form rewriter (regex/bnf.cpp) is not part of "
-                             "this build yet; use plain -match");
-}
-
-Automata* Regexp::compile(bool& is_mfa, bool use_reverse, bool use_bnf, bool use_ssnf, bool) {   // regex.cpp:266-343
+Automata* Regexp::compile(bool& is_mfa, bool use_reverse, bool use_bnf, bool use_ssnf, bool use_log) {   // regex.cpp:266-343
     is_backref_correct();
     BinaryTree* bt = to_binary_tree();
     if (!maybe_initialized.empty() || !maybe_read.empty()) {
@@ -336,12 +277,27 @@ Automata* Regexp::compile(bool& is_mfa, bool use_reverse, bool use_bnf, bool use
                 "\xd0\xbf\xd0\xb0\xd0\xbc\xd1\x8f\xd1\x82\xd1\x8c" << endl;
         is_mfa = true;
         const bool one_unamb = bt->is_one_unambiguity();
-        if ((!one_unamb && use_reverse) || use_bnf) bnf();           // throws: not in this build
+        // use_ssnf on these paths: the reference computes toSSNF() and throws the result away (regex.cpp:284,292,309)
+        if (!one_unamb && use_reverse) {
+            Regexp* normal = bnf(use_log);
+            if (normal->is_bad_bnf) {                                // not reversible in this version: the plain automaton
+                MFA* m = bt->toMFA();
+                m->draw("mfa");
+                return m;
+            }
+            cout << "BNF: " << normal->to_string() << endl;
+            Regexp* back = normal->reverse();
+            cout << "Reverse: " << back->to_string() << endl;
+            MFA* m = back->to_binary_tree()->toMFA();
+            m->is_reversed = true;
+            m->draw("reverse_mfa");
+            return m;
+        }
         if (one_unamb) {
             cout << "1-\xd0\xbe\xd0\xb4\xd0\xbd\xd0\xbe\xd0\xb7\xd0\xbd\xd0\xb0\xd1\x87\xd0\xbd\xd0\xbe\xd1\x81\xd1\x82\xd1\x8c" << endl;
             is_one_unamb = true;
         }
-        // use_ssnf: the reference computes toSSNF() here and throws the result away (regex.cpp:308-309)
+        if (use_bnf) bt = bnf(use_log)->to_binary_tree();
         MFA* m = bt->toMFA();
         m->draw("mfa");
         return m;

@@ -101,9 +101,20 @@ int main(int argc, char* argv[]) {
             match(regex, reverse, bnf, ssnf, use_log);
             return 0;
         }
-        std::cerr << "diploma: only -match is implemented in this build (the BNF/Reverse REPL of main.cpp:50-85 needs "
-                     "regex/bnf.cpp, not restated yet)\n";
-        return 2;
+        // main.cpp:50-85: no mode flag -> one regex token per round: its backreference normal form and the reversal of that.
+        // (The reference never leaves this loop: parse_regexp erases the token before it is compared with "exit", and at end of
+        // input it spins.  Here `exit` and end of input end it.)
+        const bool use_log = argc > 2 && std::strcmp(argv[2], "-log") == 0;
+        string token;
+        while (cin >> token && token != "exit") {
+            Regexp* regexp = Regexp::parse_regexp(token);
+            regexp->is_backref_correct();
+            Regexp* normal = regexp->bnf(use_log);
+            if (normal->is_bad_bnf) continue;
+            cout << "BNF: " << normal->to_string() << endl;
+            cout << "Reverse: " << normal->reverse()->to_string() << endl;
+        }
+        return 0;
     } catch (const std::exception& e) {
         std::cerr << "diploma: " << e.what() << "\n";
         return 1;

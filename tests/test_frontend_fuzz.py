@@ -67,6 +67,65 @@ def test_random_regexes_match_reference(seed, tmp_path):
     assert checked > 40
 
 
+def rand_memory_regex(rng, depth, cells):
+    """random regexes with nested initialisations, reads inside initialisations and up to three cells: what the BNF rewriter's
+    distribute / open-Kleene / denesting / sliding steps key on"""
+    if depth <= 0:
+        if cells and rng.random() < 0.35:
+            return "&" + rng.choice(cells)
+        return rng.choice("abc")
+    kind = rng.random()
+    if kind < 0.35:
+        return "".join(rand_memory_regex(rng, depth - 1, cells) for _ in range(rng.randint(2, 3)))
+    if kind < 0.55:
+        return "(" + "|".join(rand_memory_regex(rng, depth - 1, cells) for _ in range(rng.randint(2, 3))) + ")"
+    if kind < 0.72:
+        return "(" + rand_memory_regex(rng, depth - 1, cells) + ")*"
+    if kind < 0.92:
+        k = rng.choice("123")
+        inner = rand_memory_regex(rng, depth - 1, [c for c in cells if c != k])
+        if k not in cells:
+            cells.append(k)
+        return "{" + inner + "}:" + k
+    return rng.choice("abc") + "*"
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_bnf_and_reverse_match_reference(seed, tmp_path):
+    """The rewritten regexes as strings (the reference's REPL) and the automata `-bnf` / `-reverse` build from them, against
+    the reference on random regexes.  Cases on which the reference itself dies (null dereferences in its rewriter) are skipped;
+    on everything it survives this build must give the same and must not throw."""
+    rng = random.Random(7000 + seed)
+    strings_ok = images_ok = 0
+    for _ in range(120):
+        regex = rand_memory_regex(rng, rng.randint(1, 4), [])
+        if "{" not in regex and "&" not in regex:
+            continue
+        try:
+            b = subprocess.run([HARNESS, "front", regex], capture_output=True, text=True, cwd=tmp_path, timeout=20)
+        except subprocess.TimeoutExpired:
+            continue
+        if b.returncode != 0:
+            continue
+        a = subprocess.run([DIPLOMA], input=regex + "\nexit\n", capture_output=True, text=True, cwd=tmp_path, timeout=20)
+        assert a.returncode == 0, (regex, a.stderr)
+        want = "\n".join(ln for ln in b.stdout.split("\n") if ln != "BAD")       # the harness's own marker for is_bad_bnf
+        assert a.stdout == want, "regex %r" % regex
+        strings_ok += 1
+        for flag, mode in ((["-bnf"], "bnf"), (["-reverse"], "reverse")):
+            try:
+                d = subprocess.run([HARNESS, "dump", mode, regex], capture_output=True, text=True, cwd=tmp_path, timeout=20)
+            except subprocess.TimeoutExpired:
+                continue
+            if d.returncode != 0 or "UNKNOWN" in d.stdout:
+                continue
+            m = subprocess.run([DIPLOMA, "-dump"] + flag, input=regex + "\n", capture_output=True, text=True, cwd=tmp_path, timeout=20)
+            assert m.returncode == 0, (regex, mode, m.stderr)
+            assert m.stdout == d.stdout, "regex %r mode %s" % (regex, mode)
+            images_ok += 1
+    assert strings_ok > 40 and images_ok > 60
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_restatement_on_random_regexes(seed, tmp_path):
     """The CPU restatement against the reference on automata and strings outside the committed fixtures."""

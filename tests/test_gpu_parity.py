@@ -66,7 +66,8 @@ def test_cli_match_contract(tmp_path):
     (main.cpp:42-44, matchers/match.cpp:21-31)."""
     import subprocess
     diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
-    for name in ("ex1_plain", "ex5_plain", "nfa_abb_plain", "nfa_third_plain"):
+    flags = {"plain": [], "bnf": ["-bnf"], "reverse": ["-reverse"]}
+    for name in ("ex1_plain", "ex5_plain", "nfa_abb_plain", "nfa_third_plain", "ex3_reverse", "ex6_reverse", "ex2_bnf", "ex1_reverse"):
         auto = next(a for a in MANIFEST["automata"] if a["name"] == name)
         strings, want = [], []
         for sset in auto["sets"]:
@@ -75,10 +76,38 @@ def test_cli_match_contract(tmp_path):
                 if s:                              # the empty string cannot be a token of `cin >> text`
                     strings.append(s); want.append(b)
         text = auto["regex"].encode() + b"\n" + b"\n".join(strings) + b"\nexit\nnot-read\n"
-        p = subprocess.run([diploma, "-match"], input=text, capture_output=True, cwd=tmp_path)
+        p = subprocess.run([diploma, "-match"] + flags[auto["mode"]], input=text, capture_output=True, cwd=tmp_path)
         assert p.returncode == 0, p.stderr
         expect = auto["header"].encode() + b"".join(b"%d\n" % b for b in want)
         assert p.stdout == expect, name
+
+
+def test_match_file_drivers(tmp_path):
+    """`match_mfa` / `match_gt` (matchers/match_mfa.cpp:13-97): strings from a file, one batch on the GPU.  match_mfa prints the
+    batch time and then one 0/1 line per string (the reference prints `<seconds> <result>` per string); match_gt prints times
+    only, like the reference, and leaves results.txt."""
+    import subprocess
+    diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
+    for name in ("ex6_plain", "ex3_plain"):
+        auto = next(a for a in MANIFEST["automata"] if a["name"] == name)
+        strings, want = [], []
+        for sset in auto["sets"]:
+            for st, b in zip(oracle_lib.load_set(sset), oracle_lib.load_bits(name, sset)):
+                if b"\n" not in st:
+                    strings.append(st); want.append(int(b))
+        path = tmp_path / (name + ".txt")
+        path.write_bytes(b"".join(st + b"\n" for st in strings))
+        p = subprocess.run([diploma, "-match-file", "mfa", str(path)], input=auto["regex"].encode() + b"\n", capture_output=True, cwd=tmp_path)
+        assert p.returncode == 0, p.stderr
+        lines = p.stdout.split()
+        assert float(lines[0]) >= 0.0 and [int(x) for x in lines[1:]] == want, name
+        assert (tmp_path / "results7.txt").exists()
+    auto = next(a for a in MANIFEST["automata"] if a["name"] == "nfa_abb_glushkov")
+    path = tmp_path / "gt.txt"
+    path.write_bytes(b"abb\naabb\nab\nbbbbabb\n")
+    p = subprocess.run([diploma, "-match-file", "gt", str(path)], input=auto["regex"].encode() + b"\n", capture_output=True, cwd=tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert float(p.stdout.split()[0]) >= 0.0 and (tmp_path / "results.txt").exists()
 
 
 def test_cli_example_runner(tmp_path):
@@ -99,6 +128,9 @@ def test_cli_example_runner(tmp_path):
         assert p.stdout.splitlines()[0] == regex
         lines = (d / "diploma_results.txt").read_text().split("\n")
         assert lines[-1] == "" and len(lines) > 10
+        for other in ("diploma_bnf_results.txt", "diploma_reverse_results.txt"):       # the -bnf and -reverse curves (example_runner.cpp:109-111)
+            more = (d / other).read_text().split("\n")
+            assert more[-1] == "" and [ln.split()[0] for ln in more[:-1]] == [ln.split()[0] for ln in lines[:len(more) - 1]] and len(more) > 10
         want, grown, size, rnd = [], prefix, 500, 0
         while True:
             grown = grown + corpus.pumped_string(size, pump) + suffix
