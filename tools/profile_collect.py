@@ -17,35 +17,45 @@ bench = json.loads(line)
 with open(os.path.join(dst, tag + "_bench.json"), "w") as f:
     f.write(line + "\n")
 
-def pmc_sum(counter):
-    rows = [r for r in csv.DictReader(open(one(counter + "/**/*counter_collection.csv")))
-            if r["Kernel_Name"].startswith("mfa_jit_kernel") and r["Counter_Name"] == counter]
-    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    n = bench_n_examples
-    assert len(rows) >= n, (counter, len(rows))
-    return sum(float(r["Counter_Value"]) for r in rows[-n:]), len(rows)       # the last step's dispatches (earlier ones: calibration pass)
+n_walk = len(bench["per_example"])
+n_region = bench["roofline"]["region_scan_kernel"]["launches_per_step"]
 
-bench_n_examples = len(bench["per_example"])
-fetch, n_f = pmc_sum("FETCH_SIZE")
-write, n_w = pmc_sum("WRITE_SIZE")
+
+def pmc_sum(counter):
+    """the counter summed over the dispatches of the run's LAST step: its region launches and its walk launches (the run's
+    earlier dispatches are the untimed set-up pass)"""
+    rows = [r for r in csv.DictReader(open(one(counter + "/**/*counter_collection.csv"))) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    walk = [r for r in rows if r["Kernel_Name"].startswith("mfa_jit_kernel")]
+    region = [r for r in rows if "region_scan_kernel" in r["Kernel_Name"]]
+    assert len(walk) >= n_walk and len(region) >= n_region, (counter, len(walk), len(region))
+    return (sum(float(r["Counter_Value"]) for r in region[-n_region:]), sum(float(r["Counter_Value"]) for r in walk[-n_walk:]),
+            len(region) + len(walk))
+
+
+fetch_r, fetch_w, n_f = pmc_sum("FETCH_SIZE")
+write_r, write_w, n_w = pmc_sum("WRITE_SIZE")
+fetch, write = fetch_r + fetch_w, write_r + write_w
 alg = bench["roofline"]["algorithmic_bytes_per_step"]
 cfg = bench["config"]
 traffic = {
-    "round": 1, "tag": tag,
+    "round": 2, "tag": tag,
     "workload": {"strings_per_example": cfg.get("strings_per_example", 125000), "min_len": cfg.get("min_len", 1024),
                  "max_len": cfg.get("max_len", 65536), "n_gpus": bench["n_gpus"]},
     "how": "two separate rocprofv3 --pmc passes over `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary` (FETCH_SIZE, then "
-           "WRITE_SIZE), summed over the %d mfa_jit_kernel dispatches of the timed step (the run's earlier %d dispatches are the untimed "
-           "set-up passes: calibration and stream-count selection); units are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the bytes of wide coalesced "
-           "reads; confirmed on dfa_tiled_kernel: 1 GiB read -> 528 695 KiB reported = 0.504x)" % (bench_n_examples, n_f - bench_n_examples),
+           "WRITE_SIZE), summed over the %d region_scan_kernel and %d mfa_jit_kernel dispatches of the timed step (the run's earlier "
+           "dispatches are the untimed set-up pass); units are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half the "
+           "bytes of wide coalesced reads)" % (n_region, n_walk),
     "fetch_size_kib": fetch, "write_size_kib": write,
+    "region_scan_kernel": {"fetch_size_kib": fetch_r, "write_size_kib": write_r, "hbm_bytes": int(2 * fetch_r * 1024 + write_r * 1024)},
+    "mfa_jit_kernel": {"fetch_size_kib": fetch_w, "write_size_kib": write_w, "hbm_bytes": int(2 * fetch_w * 1024 + write_w * 1024)},
     "hbm_bytes_per_step": int(2 * fetch * 1024 + write * 1024),
     "algorithmic_bytes_per_step": alg,
 }
 with open(os.path.join(dst, tag + "_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
     f.write("\n")
-span = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "span_from_trace.py"), one("stats/**/*kernel_trace.csv")],
+span = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "span_from_trace.py"), one("stats/**/*kernel_trace.csv"), str(n_region), str(n_walk)],
                       capture_output=True, text=True).stdout
 with open(os.path.join(dst, tag + "_span_check.txt"), "w") as f:
     f.write(span)
