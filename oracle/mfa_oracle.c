@@ -215,6 +215,9 @@ static void m_eval_state(mctx_t* c, mstate_t st, int64_t i, sset_t* out) {
     }
 }
 
+static int g_tie_last = 0;
+void mfa_oracle_set_tie_policy(int last_wins) { g_tie_last = last_wins; }
+
 static int match_mfa(const mfa_oracle_image* img, const uint8_t* str, int64_t len, mfa_oracle_stats* stats) {
     mctx_t c; memset(&c, 0, sizeof c);
     c.img = img; c.str = str; c.len = len; c.reversed = (int)img->h.is_reversed; c.st = stats;
@@ -230,6 +233,10 @@ static int match_mfa(const mfa_oracle_image* img, const uint8_t* str, int64_t le
         for (size_t k = 0; k < cur.n; k++) {                                     /* mfa.cpp:203-213 */
             mstate_t s = cur.v[k];
             if (!visited[s.node]) {
+                /* fixture classification only (tests/golden/classify.py): let the LAST of the states that tie on
+                 * (pos, node) win instead of the first, to see whether the answer depends on the tie-break at all */
+                if (g_tie_last)
+                    while (k + 1 < cur.n && cur.v[k + 1].node == s.node && cur.v[k + 1].pos == s.pos) s = cur.v[++k];
                 visited[s.node] = 1;
                 if (stats) stats->evaluations++;
                 m_eval_state(&c, s, i, &nxt);

@@ -47,4 +47,8 @@ int  mfa_oracle_match_batch(const mfa_oracle_image* img, const uint8_t* bytes, c
 #ifdef __cplusplus
 }
 #endif
+/* 0 (default): the reference's rule, the first state per node in set order wins (mfa.cpp:206-211).  1: among the states that
+ * tie on (pos, node) the last one wins -- only used to classify fixtures as tie-sensitive or not. */
+void mfa_oracle_set_tie_policy(int last_wins);
+
 #endif

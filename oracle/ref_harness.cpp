@@ -76,7 +76,11 @@ static void big_free(void* p) {
     free(h);
 }
 
+// REF_HARNESS_ALLOC=glibc: no arena -- the reference on glibc's heap, as a user runs it (fixture class C: where that differs)
+static const bool g_glibc = getenv("REF_HARNESS_ALLOC") && !strcmp(getenv("REF_HARNESS_ALLOC"), "glibc");
+
 void* operator new(size_t n) {
+    if (g_glibc) { void* p = malloc(n ? n : 1); if (!p) abort(); return p; }
     if (g_in_ref && n <= kSmall) {
         if (!g_arena) arena_init();
         size_t a = (n + 15) & ~(size_t)15;
@@ -98,6 +102,7 @@ extern "C" void free(void* p) {
 }
 void operator delete(void* p) noexcept {
     if (!p) return;
+    if (g_glibc) { __libc_free(p); return; }
     if (g_arena && (char*)p >= g_arena && (char*)p < g_arena + g_arena_cap) return;
     big_free(p);
 }
@@ -219,7 +224,7 @@ static void dump(const Compiled& c) {
 }
 
 static bool run_match(const Compiled& c, const std::string& s) {
-    arena_rewind();
+    if (!g_glibc) arena_rewind();
     g_in_ref = true;
     bool r = c.mfa ? c.mfa->match(s) : c.nfa->match(s);
     g_in_ref = false;
