@@ -514,6 +514,37 @@ dfa_tiled_kernel(DfaPacked pk, const uint16_t* __restrict__ trans, const uint8_t
     }
 }
 
+// Tabulated automata whose table does not fit LDS (more than 127 state sets): the table stays in global memory -- a few
+// hundred KiB at most, resident in L2 -- and only the byte classes go to LDS.  One string per lane, 32-bit state.
+template <bool REV>
+__global__ void __launch_bounds__(256)
+dfa_big_kernel(const uint16_t* __restrict__ trans, const uint8_t* __restrict__ accept_tab, const uint8_t* __restrict__ byte_class,
+               uint32_t n_classes, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
+               uint8_t* __restrict__ results) {
+    __shared__ uint8_t s_class[256];
+    s_class[threadIdx.x] = byte_class[threadIdx.x];
+    __syncthreads();
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t sid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; sid < n; sid += stride) {
+        const uint64_t b = offsets[sid], e = offsets[sid + 1];
+        uint32_t st = 1u;                                             // state 1 = {start}, state 0 = the empty set
+        uint64_t p = REV ? e : b;
+        while ((REV ? p > b : p < e) && st != 0u) {
+            const uint64_t blk = (REV ? p - 1u : p) & ~(uint64_t)15;
+            const uint4 d = load16(bytes, blk);
+            const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+            const uint32_t lo = b > blk ? (uint32_t)(b - blk) : 0u, hi = (e - blk) < 16u ? (uint32_t)(e - blk) : 16u;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int k = REV ? 15 - j : j;
+                if ((uint32_t)k >= lo && (uint32_t)k < hi) st = trans[st * n_classes + s_class[(w[k >> 2] >> (8 * (k & 3))) & 0xffu]];
+            }
+            p = REV ? blk : blk + 16u;
+        }
+        results[sid] = accept_tab[st];
+    }
+}
+
 // ---- launchers ------------------------------------------------------------------------------------
 template <int K, bool REV>
 static int launch_mfa_k(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
@@ -565,6 +596,11 @@ int launch_mfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const 
         case 2: return launch_mfa_rev<2>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
         case 3: return launch_mfa_rev<3>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
         case 4: return launch_mfa_rev<4>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
+        case 5: return launch_mfa_rev<5>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
+        case 6: return launch_mfa_rev<6>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
+        case 7: return launch_mfa_rev<7>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
+        case 8: return launch_mfa_rev<8>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
+        case 9: return launch_mfa_rev<9>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
     }
     return MFA_ERR_UNSUPPORTED;
 }
@@ -609,7 +645,21 @@ static int launch_dfa_tiled(const HostImage& img, DeviceState& ds, LaunchCtx& cx
 int launch_dfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream) {
     hipStream_t s = (hipStream_t)stream;
-    if ((size_t)img.dfa_states * kDfaRow > 0xffffu) return MFA_ERR_UNSUPPORTED;      // 16-bit pre-multiplied states
+    if ((size_t)img.dfa_states * kDfaRow > 0xffffu) {                               // beyond 16-bit pre-multiplied states: table in L2
+        uint64_t blocks = (n + 255) / 256, cap = (uint64_t)ds.n_cus * 8;
+        if (blocks > cap) blocks = cap;
+        if (blocks == 0) blocks = 1;
+        HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_start, s));
+        if (img.h.is_reversed)
+            hipLaunchKernelGGL(dfa_big_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, ds.d_dfa_trans, ds.d_dfa_accept, ds.d_byte_class,
+                               img.n_classes, d_bytes, d_offsets, n, d_results);
+        else
+            hipLaunchKernelGGL(dfa_big_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, ds.d_dfa_trans, ds.d_dfa_accept, ds.d_byte_class,
+                               img.n_classes, d_bytes, d_offsets, n, d_results);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_stop, s));
+        return MFA_OK;
+    }
     {
         const char* mode = getenv("MFA_DFA_KERNEL");                                 // "simple" selects the untiled walk
         if (!(mode && mode[0] == 's')) {

@@ -404,3 +404,42 @@ def test_acceleration_changes_nothing_on_the_bench_corpus(ex, monkeypatch):
     strings = corpus.host_strings(ex, sizes[short], ws[short])
     want = oracle_lib.OracleImage(blob).match(strings)
     assert list(fast[short].cpu().numpy()) == list(want)
+
+
+MANY_CELLS = ["{a*}:1{b*}:2{c*}:3{a*}:4{b*}:5&5&4&3&2&1", "{a}:1{b}:2{c}:3{a*}:4{b*}:5{c*}:6{a}:7{b}:8{c*}:9&9&8&7&6&5&4&3&2&1"]
+
+
+@pytest.mark.parametrize("regex", MANY_CELLS, ids=["5cells", "9cells"])
+def test_more_than_four_cells(regex, tmp_path, monkeypatch):
+    """cells "1".."9" (mfa.cpp:148): automata with five and nine cells on both kernels against the CPU restatement"""
+    import random
+    blob = _front_end_blob(regex, tmp_path)
+    assert image.blob_info(blob)["n_cells"] == (5 if regex.startswith("{a*}") else 9)
+    rng = random.Random(len(regex))
+    strings = [b"", b"abcab" + b"bacba"[::-1], b"aabbccaabb" + b"bbaaccbbaa"]
+    for _ in range(300):
+        parts = ["a" * rng.randint(0, 3), "b" * rng.randint(0, 3), "c" * rng.randint(0, 3), "a" * rng.randint(0, 3), "b" * rng.randint(0, 3)]
+        s = "".join(parts) + "".join(reversed(parts)) if rng.random() < 0.5 else "".join(rng.choice("abc") for _ in range(rng.randint(0, 24)))
+        strings.append(s.encode())
+    strings += [b"abcaabbccabc" + b"cbccbbaacba"[::-1], b"abc" + b"a" * 40 + b"b" * 30 + b"c" * 20 + b"ab" + b"c" * 20 + b"ba" + b"c" * 20 + b"b" * 30 + b"a" * 40 + b"cba"]
+    want = oracle_lib.OracleImage(blob).match(strings)
+    for mode in ("generic", "specialised"):
+        monkeypatch.setenv("MFA_JIT", "0" if mode == "generic" else "1")
+        got = gpu_match(capi.Image(blob), strings)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "%s: %d mismatches, first %r want %d" % (mode, bad.size, strings[bad[0]], want[bad[0]])
+    assert want.sum() > 0
+
+
+def test_large_tabulated_automaton(tmp_path):
+    """a memory-less automaton whose subset construction has hundreds of state sets (the table does not fit LDS): Thompson image
+    of (a|b)*a(a|b)^8, forward walk, against the CPU restatement"""
+    regex = "(a|b)*a" + "(a|b)" * 8
+    blob = _front_end_blob(regex, tmp_path, "-thompson")
+    img = capi.Image(blob)
+    assert img.info()["dfa_states"] > 127
+    rng = np.random.default_rng(99)
+    strings = [bytes(rng.choice(list(b"ab"), size=int(n)).tolist()) for n in rng.integers(0, 300, size=600)] + [b"", b"a" + b"b" * 8, b"b" * 9]
+    want = oracle_lib.OracleImage(blob).match(strings)
+    got = gpu_match(img, strings)
+    assert np.array_equal(got, want) and 0 < want.sum() < len(strings)
