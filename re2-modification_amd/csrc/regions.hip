@@ -146,260 +146,223 @@ __device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, uint3
     book<Q>(st, lane, __ballot((mask & qbit(Q)) != 0u), base);
 }
 
-// MODE 1: streaming phase only (development).  PF: rows whose loads are in flight beyond the one being looked at.
-// DPP: the 8 bytes behind a block come from the neighbouring lane's registers (lane 63: from the next row's lane 0) instead
-// of a second load.
-template <int MODE, int PF, bool DPP, int GRP>
-__global__ void __launch_bounds__(256, (GRP >= 8 ? 4 : GRP >= 4 ? 6 : 8)) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
-                                                          uint64_t* __restrict__ table) {
-    constexpr int NB = PF + 1;
+// ---- one string ---------------------------------------------------------------------------------------------
+struct Geo {                 // where a string lies: blocks are the 16-byte aligned blocks of the batch it touches
+    uint64_t a0;             // offset of block 0 in the batch
+    uint32_t off0, len;      // the string starts off0 bytes into block 0
+    int32_t nblk, endblk, nrows;
+};
+
+__device__ __forceinline__ Geo make_geo(uint64_t b, uint64_t e) {
+    Geo g;
+    g.len = (uint32_t)(e - b);
+    g.a0 = b & ~(uint64_t)15;
+    g.off0 = (uint32_t)(b - g.a0);
+    g.nblk = (int32_t)((g.off0 + g.len + 15u) >> 4);
+    g.endblk = g.len >= 8u ? (int32_t)((g.off0 + g.len - 8u) >> 4) : 0;
+    g.nrows = (g.nblk + 63) >> 6;
+    return g;
+}
+
+struct Scan {
+    RegionState st;
+    // Rows whose blocks all carry the same mask as the row before (a stretch inside one periodic region, or text in which every
+    // block is dirty for every period) need no book-keeping at all.  `settled` is that mask (~0u: the last row was not uniform),
+    // vp the smallest clean period in it (0: none); the dirty periods' last_dirty is caught up when the stretch ends.
+    uint32_t settled, vp;
+};
+
+__device__ __forceinline__ void scan_reset(Scan& sc) {
+#pragma unroll
+    for (int q = 0; q < 9; q++) { sc.st.last_dirty[q] = -1; sc.st.cand_x[q] = 0x7fffffff; sc.st.cand_y[q] = -1; }
+    sc.st.ncand = 0; sc.st.cq = 0; sc.st.cx = 0; sc.st.cy = 0;
+    sc.settled = ~0u; sc.vp = 0u;
+}
+
+// No branch around the loads (the compiler then counts them and waits for the older pair only): rows are read whole, lanes
+// past the last block re-read it, and the 8 bytes behind the very last block of the batch come from inside it; what such lanes
+// load is never looked at (their blocks are forced).
+__device__ __forceinline__ void load_row(const uint8_t* bytes, const Geo& g, uint64_t ymax, int32_t row, uint32_t lane, uint4& x, uint2& y) {
+    row = row < g.nrows ? row : g.nrows - 1;
+    int32_t blk = row * 64 + (int32_t)lane;
+    blk = blk < g.nblk ? blk : g.nblk - 1;
+    const uint64_t addr = g.a0 + 16u * (uint64_t)blk;
+    const uint64_t ya = addr + 16u <= ymax ? addr + 16u : ymax;
+    x = *reinterpret_cast<const uint4*>(bytes + addr);
+    y = *reinterpret_cast<const uint2*>(bytes + ya);
+}
+
+// one row: x = this lane's block, y = the 8 bytes behind it
+__device__ __forceinline__ void scan_row(Scan& sc, uint32_t lane, const Geo& g, const int32_t row, const uint4 x, const uint2 y) {
+    RegionState& st = sc.st;
+    const int32_t base = row * 64, blk = base + (int32_t)lane;
+    const bool forced = blk == 0 || blk >= g.endblk;
+    // Inside a stretch with a clean period (vp = the smallest one) a row looks like the one before as soon as the 24 bytes every
+    // lane holds are vp-periodic: the stretch then continues with the same word, and whether a block is dirty for a period
+    // depends on that word only.
+    const uint32_t vp = sc.vp;
+    if (vp != 0u) {
+        uint32_t s0, s1, s2, s3;
+        if (vp < 4u) {
+            s0 = __builtin_amdgcn_alignbyte(x.y, x.x, vp); s1 = __builtin_amdgcn_alignbyte(x.z, x.y, vp);
+            s2 = __builtin_amdgcn_alignbyte(x.w, x.z, vp); s3 = __builtin_amdgcn_alignbyte(y.x, x.w, vp);
+        } else if (vp < 8u) {
+            s0 = __builtin_amdgcn_alignbyte(x.z, x.y, vp - 4u); s1 = __builtin_amdgcn_alignbyte(x.w, x.z, vp - 4u);
+            s2 = __builtin_amdgcn_alignbyte(y.x, x.w, vp - 4u); s3 = __builtin_amdgcn_alignbyte(y.y, y.x, vp - 4u);
+        } else { s0 = x.z; s1 = x.w; s2 = y.x; s3 = y.y; }
+        uint32_t diff = (x.x ^ s0) | (x.y ^ s1) | (x.z ^ s2) | (x.w ^ s3);
+        if (vp < 8u) {                                 // bytes 16..23 among themselves
+            const uint64_t yy = ((uint64_t)y.y << 32) | y.x;
+            const uint64_t dd = (yy ^ (yy >> (8u * vp))) << (8u * vp);      // the low 8 - vp bytes of the difference
+            diff |= (uint32_t)dd | (uint32_t)(dd >> 32);
+        }
+        if (!__any(forced || diff != 0u)) return;
+    }
+    const uint32_t mask = forced ? kAllDirty : block_mask(x.x, x.y, x.z, x.w, y.x, y.y);
+    if (__all(mask == sc.settled)) return;
+    const uint32_t was = sc.settled != ~0u ? sc.settled : 0u;
+    row_period<1>(st, lane, mask, was, base);
+    row_period<2>(st, lane, mask, was, base);
+    row_period<3>(st, lane, mask, was, base);
+    row_period<4>(st, lane, mask, was, base);
+    row_period<5>(st, lane, mask, was, base);
+    row_period<6>(st, lane, mask, was, base);
+    row_period<7>(st, lane, mask, was, base);
+    row_period<8>(st, lane, mask, was, base);
+    const uint32_t m0 = __builtin_amdgcn_readfirstlane(mask);
+    sc.settled = __all(mask == m0) ? m0 : ~0u;
+    sc.vp = 0u;
+    if (sc.settled != ~0u) {
+#pragma unroll
+        for (int q = 8; q >= 1; q--)
+            if (!(sc.settled & qbit(q))) sc.vp = (uint32_t)q;
+    }
+}
+
+// exact ends of the candidates, clean-up, table row
+__device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo& g, const uint8_t* bytes, uint64_t total16, uint64_t* tab) {
+    RegionState& st = sc.st;
+    // ---- exact ends: lane c resolves candidate c against the real bytes
+    const uint32_t ncand = st.ncand < 64u ? st.ncand : 64u;
+    bool keep = false;
+    uint32_t lo = 0, hi = 0;
+    const uint32_t q = st.cq;
+    if (lane < ncand) {
+        const int64_t vlo = (int64_t)g.off0, vhi = (int64_t)g.off0 + (int64_t)g.len - (int64_t)q;   // valid j (relative to a0): vlo <= j < vhi
+        auto ld8 = [&](uint64_t addr) -> uint64_t {
+            uint64_t v = 0;
+            if (addr + 8u <= total16) v = *reinterpret_cast<const uint64_t*>(bytes + addr);
+            return v;
+        };
+        {   // the last real mismatch in block X, or the first valid position of X
+            const uint64_t addr = g.a0 + 16u * (uint64_t)st.cx;
+            const uint64_t p0 = ld8(addr), p1 = ld8(addr + 8u), p2 = ld8(addr + 16u);
+            uint32_t m = nz8(p0 ^ shr_bytes(p0, p1, q)) | (nz8(p1 ^ shr_bytes(p1, p2, q)) << 8);
+            const int64_t w0 = 16 * (int64_t)st.cx;
+            uint32_t valid = 0xffffu;
+            if (vlo > w0) valid &= vlo - w0 >= 16 ? 0u : (0xffffu << (uint32_t)(vlo - w0));
+            if (vhi < w0 + 16) valid &= vhi <= w0 ? 0u : (0xffffu >> (uint32_t)(w0 + 16 - vhi));
+            m &= valid;
+            const int64_t lo_abs = m ? w0 + (31 - __builtin_clz(m)) + 1 : (w0 > vlo ? w0 : vlo);
+            lo = (uint32_t)(lo_abs - vlo);
+        }
+        {   // the first real mismatch in blocks Y, Y + 1
+            const uint64_t addr = g.a0 + 16u * (uint64_t)st.cy;
+            const uint64_t p0 = ld8(addr), p1 = ld8(addr + 8u), p2 = ld8(addr + 16u), p3 = ld8(addr + 24u), p4 = ld8(addr + 32u);
+            uint32_t m = nz8(p0 ^ shr_bytes(p0, p1, q)) | (nz8(p1 ^ shr_bytes(p1, p2, q)) << 8) | (nz8(p2 ^ shr_bytes(p2, p3, q)) << 16) |
+                         (nz8(p3 ^ shr_bytes(p3, p4, q)) << 24);
+            const int64_t w0 = 16 * (int64_t)st.cy;
+            uint32_t valid = 0xffffffffu;
+            if (vhi < w0 + 32) valid = vhi <= w0 ? 0u : (0xffffffffu >> (uint32_t)(w0 + 32 - vhi));
+            m &= valid;
+            int64_t hi_abs;
+            if (m) hi_abs = w0 + __builtin_ctz(m) + (int64_t)q;
+            else if (vhi < w0 + 32) hi_abs = vlo + (int64_t)g.len;
+            else hi_abs = w0 + 32 + (int64_t)q;
+            hi = (uint32_t)(hi_abs - vlo);
+        }
+        keep = hi > lo && hi - lo >= MFA_REGION_MIN_LEN && hi <= g.len;
+    }
+    // ---- drop regions that a region of a divisor period covers
+    for (uint32_t f = 0; f < ncand; f++) {
+        const uint32_t qf = __shfl(q, (int)f), lof = __shfl(lo, (int)f), hif = __shfl(hi, (int)f);
+        const bool kf = __shfl((int)keep, (int)f) != 0;
+        if (!kf) continue;
+        const bool divides = ((0x804020108824aaffull >> (((qf - 1u) * 8u + (q - 1u)) & 63u)) & 1ull) != 0ull;     // bit 8 (qf-1) + (q-1): qf divides q
+        if (lane < ncand && lane != f && qf < q && divides && lof <= lo + 16u && hif + 16u >= hi) keep = false;
+    }
+    unsigned long long kb = __ballot(keep);
+    const uint32_t total = (uint32_t)__builtin_popcountll(kb);
+    if (total > MFA_REGION_MAX) {                          // more than fit: the longest stay
+        const uint32_t mine = hi - lo;
+        uint32_t longer = 0;
+        for (uint32_t f = 0; f < ncand; f++) {
+            const uint32_t lf = __shfl(mine, (int)f);
+            if (((kb >> f) & 1ull) && (lf > mine || (lf == mine && f < lane))) longer++;
+        }
+        keep = keep && longer < MFA_REGION_MAX;
+        kb = __ballot(keep);
+    }
+    // entries go out in the order of their starts (the walk kernels copy the first few to LDS: the ones they meet first)
+    uint32_t rank = 0;
+    {
+        const uint32_t key = (lo << 4) | q;
+        for (unsigned long long m = kb; m; m &= m - 1ull) {
+            const int f = __builtin_ctzll(m);
+            const uint32_t kf = __shfl(key, f);
+            if (kf < key || (kf == key && (uint32_t)f < lane)) rank++;
+        }
+    }
+    if (keep && rank < MFA_REGION_MAX) tab[1 + rank] = (uint64_t)lo | ((uint64_t)hi << 24) | ((uint64_t)q << 48);
+    if (lane == 0) tab[0] = (uint64_t)(total < MFA_REGION_MAX ? total : MFA_REGION_MAX) |
+                            ((total > MFA_REGION_MAX || st.ncand > 64u) ? MFA_REGION_OVERFLOW : 0ull);
+}
+
+// ---- kernels ---------------------------------------------------------------------------------------------------
+// MODE 1: streaming phase only (development).
+// One wave per string (the hardware dispatcher hands out strings), the next row's loads issued before the current row is looked
+// at.  A persistent form (as many waves as the chip holds, strings by ticket, the next string's offsets and first row requested
+// before the current string's candidates are resolved) was built and measured: 4.48 ms against 4.30 ms for this one on the
+// headline shard, and worse beside the walk kernels -- with eight waves per SIMD the dispatcher's own refill hides a wave's
+// start-up latencies as well as software pipelining does.
+template <int MODE>
+__global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
+                                                             uint64_t* __restrict__ table) {
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = (uint64_t)blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = (uint64_t)gridDim.x * 4u;
     const uint64_t total16 = (offsets[n] + 15u) & ~(uint64_t)15;        // the batch is readable below this offset
+    const uint64_t ymax = total16 - 8u;
     for (uint64_t sid = wave; sid < n; sid += n_waves) {
         const uint64_t b = offsets[sid], e = offsets[sid + 1];
         uint64_t* const tab = table + sid * MFA_REGION_WORDS;
         if (e - b > kMaxLen) { if (lane == 0) tab[0] = MFA_REGION_OVERFLOW; continue; }
-        const uint32_t len = (uint32_t)(e - b);
-        const uint64_t a0 = b & ~(uint64_t)15;
-        const uint32_t off0 = (uint32_t)(b - a0);
-        const int32_t nblk = (int32_t)((off0 + len + 15u) >> 4);
-        const int32_t endblk = len >= 8u ? (int32_t)((off0 + len - 8u) >> 4) : 0;
-        const int32_t nrows = (nblk + 63) >> 6;
-        RegionState st;
-#pragma unroll
-        for (int q = 0; q < 9; q++) { st.last_dirty[q] = -1; st.cand_x[q] = 0x7fffffff; st.cand_y[q] = -1; }
-        st.ncand = 0; st.cq = 0; st.cx = 0; st.cy = 0;
-        // Rows whose blocks all carry the same mask as the row before (a stretch inside one periodic region, or text in which
-        // every block is dirty for every period) need no book-keeping at all: one compare and one ballot.  `settled` is that
-        // mask (~0u: the last row was not uniform); the dirty periods' last_dirty is caught up when the stretch ends.
-        uint32_t settled = ~0u, vp = 0u;
-        // no branch around the loads (the compiler then counts them and waits for the oldest only): rows are read whole,
-        // lanes past the last block re-read it, and the 8 bytes behind the very last block of the batch come from inside it;
-        // what such lanes load is never looked at (their blocks are forced)
-        const uint64_t ymax = total16 - 8u;
-        auto load_row = [&](int32_t row, uint4& x, uint2& y) {
-            row = row < nrows ? row : nrows - 1;
-            int32_t blk = row * 64 + (int32_t)lane;
-            blk = blk < nblk ? blk : nblk - 1;
-            const uint64_t addr = a0 + 16u * (uint64_t)blk;
-            x = *reinterpret_cast<const uint4*>(bytes + addr);
-            if (!DPP) {
-                const uint64_t ya = addr + 16u <= ymax ? addr + 16u : ymax;
-                y = *reinterpret_cast<const uint2*>(bytes + ya);
-            }
-        };
-        // one row: x = this lane's block, y = the 8 bytes behind it
-        auto process = [&](const int32_t row, const uint4 x, const uint2 y) {
-    const int32_t base = row * 64, blk = base + (int32_t)lane;
-            const bool forced = blk == 0 || blk >= endblk;
-            // Inside a stretch with a clean period (vp = the smallest one) a row looks like the one before as soon as the 24
-            // bytes every lane holds are vp-periodic: the stretch then continues with the same word, and whether a block is
-            // dirty for a period depends on that word only.
-            if (vp != 0u) {
-                uint32_t s0, s1, s2, s3;
-                if (vp < 4u) {
-                    s0 = __builtin_amdgcn_alignbyte(x.y, x.x, vp); s1 = __builtin_amdgcn_alignbyte(x.z, x.y, vp);
-                    s2 = __builtin_amdgcn_alignbyte(x.w, x.z, vp); s3 = __builtin_amdgcn_alignbyte(y.x, x.w, vp);
-                } else if (vp < 8u) {
-                    s0 = __builtin_amdgcn_alignbyte(x.z, x.y, vp - 4u); s1 = __builtin_amdgcn_alignbyte(x.w, x.z, vp - 4u);
-                    s2 = __builtin_amdgcn_alignbyte(y.x, x.w, vp - 4u); s3 = __builtin_amdgcn_alignbyte(y.y, y.x, vp - 4u);
-                } else { s0 = x.z; s1 = x.w; s2 = y.x; s3 = y.y; }
-                uint32_t diff = (x.x ^ s0) | (x.y ^ s1) | (x.z ^ s2) | (x.w ^ s3);
-                if (vp < 8u) {                                 // bytes 16..23 among themselves
-                    const uint64_t yy = ((uint64_t)y.y << 32) | y.x;
-                    const uint64_t dd = (yy ^ (yy >> (8u * vp))) << (8u * vp);      // the low 8 - vp bytes of the difference
-                    diff |= (uint32_t)dd | (uint32_t)(dd >> 32);
-                }
-                if (!__any(forced || diff != 0u)) return;
-            }
-            const uint32_t mask = forced ? kAllDirty : block_mask(x.x, x.y, x.z, x.w, y.x, y.y);
-            if (__all(mask == settled)) return;
-            const uint32_t was = settled != ~0u ? settled : 0u;
-            row_period<1>(st, lane, mask, was, base);
-            row_period<2>(st, lane, mask, was, base);
-            row_period<3>(st, lane, mask, was, base);
-            row_period<4>(st, lane, mask, was, base);
-            row_period<5>(st, lane, mask, was, base);
-            row_period<6>(st, lane, mask, was, base);
-            row_period<7>(st, lane, mask, was, base);
-            row_period<8>(st, lane, mask, was, base);
-            const uint32_t m0 = __builtin_amdgcn_readfirstlane(mask);
-            settled = __all(mask == m0) ? m0 : ~0u;
-            vp = 0u;
-            if (settled != ~0u) {
-#pragma unroll
-                for (int q = 8; q >= 1; q--)
-                    if (!(settled & qbit(q))) vp = (uint32_t)q;
-            }
-        };
-        if (GRP == 0) {
-            uint4 xs[NB];
-            uint2 ys[NB];
-#pragma unroll
-            for (int k = 0; k < NB; k++) { xs[k] = make_uint4(0, 0, 0, 0); ys[k] = make_uint2(0, 0); }
-            if (nrows > 0) {
-#pragma unroll
-                for (int k = 0; k < PF; k++) load_row(k, xs[k], ys[k]);
-            }
-            for (int32_t row0 = 0; row0 < nrows; row0 += NB) {
-#pragma unroll
-                for (int k = 0; k < NB; k++) {
-                    const int32_t row = row0 + k;
-                    if (row >= nrows) break;
-                    load_row(row + PF, xs[(k + PF) % NB], ys[(k + PF) % NB]);      // rows ahead are on their way while this one is looked at
-                    const uint4 x = xs[k];
-                    uint2 y = ys[k];
-                    if (DPP) {                                           // lane L: the first 8 bytes of lane L + 1; lane 63: of the next row's lane 0
-                        const uint4 xn = xs[(k + 1) % NB];
-                        const uint32_t n0 = __builtin_amdgcn_readfirstlane(xn.x), n1 = __builtin_amdgcn_readfirstlane(xn.y);
-                        y.x = __builtin_amdgcn_update_dpp(n0, x.x, 0x130, 0xf, 0xf, false);      // wave_shl:1
-                        y.y = __builtin_amdgcn_update_dpp(n1, x.y, 0x130, 0xf, 0xf, false);
-                    }
-                    process(row, x, y);
-                }
-            }
-        } else {
-            // Bursts: the loads of GRP consecutive rows (GRP KiB of the string, contiguous) go out back to back -- DRAM pages and
-            // TLB entries are used whole -- while the burst before is looked at.  Two register buffers; the 8 bytes behind a burst
-            // (for lane 63 of its last row) come with it as one broadcast load.
-            constexpr int G = GRP > 0 ? GRP : 1;
-            const int32_t ngroups = (nrows + G - 1) / G;
-            auto load_group = [&](int32_t g, uint4 (&buf)[G], uint2& tail) {
-#pragma unroll
-                for (int k = 0; k < G; k++) {
-                    int32_t row = g * G + k;
-                    row = row < nrows ? row : nrows - 1;
-                    int32_t blk = row * 64 + (int32_t)lane;
-                    blk = blk < nblk ? blk : nblk - 1;
-                    buf[k] = *reinterpret_cast<const uint4*>(bytes + a0 + 16u * (uint64_t)blk);
-                }
-                uint64_t ta = a0 + 16u * 64u * (uint64_t)((g + 1) * G);
-                ta = ta <= ymax ? ta : ymax;
-                tail = *reinterpret_cast<const uint2*>(bytes + ta);
-            };
-            auto run_group = [&](int32_t g, const uint4 (&buf)[G], const uint2 tail) {
-#pragma unroll
-                for (int k = 0; k < G; k++) {
-                    const int32_t row = g * G + k;
-                    if (row >= nrows) break;
-                    const uint32_t n0 = __builtin_amdgcn_readfirstlane(k + 1 < G ? buf[(k + 1) % G].x : tail.x);
-                    const uint32_t n1 = __builtin_amdgcn_readfirstlane(k + 1 < G ? buf[(k + 1) % G].y : tail.y);
-                    uint2 y;
-                    y.x = __builtin_amdgcn_update_dpp(n0, buf[k].x, 0x130, 0xf, 0xf, false);          // wave_shl:1
-                    y.y = __builtin_amdgcn_update_dpp(n1, buf[k].y, 0x130, 0xf, 0xf, false);
-                    process(row, buf[k], y);
-                }
-            };
-            uint4 bufa[G], bufb[G];
-            uint2 ta = make_uint2(0, 0), tb = make_uint2(0, 0);
-            if (ngroups > 0) load_group(0, bufa, ta);
-            for (int32_t g = 0; g < ngroups; g += 2) {
-                load_group(g + 1 < ngroups ? g + 1 : g, bufb, tb);
-                run_group(g, bufa, ta);
-                if (g + 1 >= ngroups) break;
-                load_group(g + 2 < ngroups ? g + 2 : g + 1, bufa, ta);
-                run_group(g + 1, bufb, tb);
-            }
+        const Geo g = make_geo(b, e);
+        Scan sc;
+        scan_reset(sc);
+        uint4 x = make_uint4(0, 0, 0, 0), nx = x;
+        uint2 y = make_uint2(0, 0), ny = y;
+        if (g.nrows > 0) load_row(bytes, g, ymax, 0, lane, x, y);
+        for (int32_t row = 0; row < g.nrows; row++) {
+            load_row(bytes, g, ymax, row + 1, lane, nx, ny);            // the next row is on its way while this one is looked at
+            scan_row(sc, lane, g, row, x, y);
+            x = nx; y = ny;
         }
-        if (MODE == 1) { if (lane == 0) tab[0] = st.ncand; continue; }            // experiment: streaming phase only
-        // ---- exact ends: lane c resolves candidate c against the real bytes
-        const uint32_t ncand = st.ncand < 64u ? st.ncand : 64u;
-        bool keep = false;
-        uint32_t lo = 0, hi = 0;
-        const uint32_t q = st.cq;
-        if (lane < ncand) {
-            const int64_t vlo = (int64_t)off0, vhi = (int64_t)off0 + (int64_t)len - (int64_t)q;   // valid j (relative to a0): vlo <= j < vhi
-            auto ld8 = [&](uint64_t addr) -> uint64_t {
-                uint64_t v = 0;
-                if (addr + 8u <= total16) v = *reinterpret_cast<const uint64_t*>(bytes + addr);
-                return v;
-            };
-            {   // the last real mismatch in block X, or the first valid position of X
-                const uint64_t addr = a0 + 16u * (uint64_t)st.cx;
-                const uint64_t p0 = ld8(addr), p1 = ld8(addr + 8u), p2 = ld8(addr + 16u);
-                uint32_t m = nz8(p0 ^ shr_bytes(p0, p1, q)) | (nz8(p1 ^ shr_bytes(p1, p2, q)) << 8);
-                const int64_t w0 = 16 * (int64_t)st.cx;
-                uint32_t valid = 0xffffu;
-                if (vlo > w0) valid &= vlo - w0 >= 16 ? 0u : (0xffffu << (uint32_t)(vlo - w0));
-                if (vhi < w0 + 16) valid &= vhi <= w0 ? 0u : (0xffffu >> (uint32_t)(w0 + 16 - vhi));
-                m &= valid;
-                const int64_t lo_abs = m ? w0 + (31 - __builtin_clz(m)) + 1 : (w0 > vlo ? w0 : vlo);
-                lo = (uint32_t)(lo_abs - vlo);
-            }
-            {   // the first real mismatch in blocks Y, Y + 1
-                const uint64_t addr = a0 + 16u * (uint64_t)st.cy;
-                const uint64_t p0 = ld8(addr), p1 = ld8(addr + 8u), p2 = ld8(addr + 16u), p3 = ld8(addr + 24u), p4 = ld8(addr + 32u);
-                uint32_t m = nz8(p0 ^ shr_bytes(p0, p1, q)) | (nz8(p1 ^ shr_bytes(p1, p2, q)) << 8) | (nz8(p2 ^ shr_bytes(p2, p3, q)) << 16) |
-                             (nz8(p3 ^ shr_bytes(p3, p4, q)) << 24);
-                const int64_t w0 = 16 * (int64_t)st.cy;
-                uint32_t valid = 0xffffffffu;
-                if (vhi < w0 + 32) valid = vhi <= w0 ? 0u : (0xffffffffu >> (uint32_t)(w0 + 32 - vhi));
-                m &= valid;
-                int64_t hi_abs;
-                if (m) hi_abs = w0 + __builtin_ctz(m) + (int64_t)q;
-                else if (vhi < w0 + 32) hi_abs = vlo + (int64_t)len;
-                else hi_abs = w0 + 32 + (int64_t)q;
-                hi = (uint32_t)(hi_abs - vlo);
-            }
-            keep = hi > lo && hi - lo >= MFA_REGION_MIN_LEN && hi <= len;
-        }
-        // ---- drop regions that a region of a divisor period covers
-        for (uint32_t f = 0; f < ncand; f++) {
-            const uint32_t qf = __shfl(q, (int)f), lof = __shfl(lo, (int)f), hif = __shfl(hi, (int)f);
-            const bool kf = __shfl((int)keep, (int)f) != 0;
-            if (!kf) continue;
-            const bool divides = ((0x804020108824aaffull >> (((qf - 1u) * 8u + (q - 1u)) & 63u)) & 1ull) != 0ull;     // bit 8 (qf-1) + (q-1): qf divides q
-            if (lane < ncand && lane != f && qf < q && divides && lof <= lo + 16u && hif + 16u >= hi) keep = false;
-        }
-        unsigned long long kb = __ballot(keep);
-        const uint32_t total = (uint32_t)__builtin_popcountll(kb);
-        if (total > MFA_REGION_MAX) {                          // more than fit: the longest stay
-            const uint32_t mine = hi - lo;
-            uint32_t longer = 0;
-            for (uint32_t f = 0; f < ncand; f++) {
-                const uint32_t lf = __shfl(mine, (int)f);
-                if (((kb >> f) & 1ull) && (lf > mine || (lf == mine && f < lane))) longer++;
-            }
-            keep = keep && longer < MFA_REGION_MAX;
-            kb = __ballot(keep);
-        }
-        // entries go out in the order of their starts (the walk kernels copy the first few to LDS: the ones they meet first)
-        uint32_t rank = 0;
-        {
-            const uint32_t key = (lo << 4) | q;
-            for (unsigned long long m = kb; m; m &= m - 1ull) {
-                const int f = __builtin_ctzll(m);
-                const uint32_t kf = __shfl(key, f);
-                if (kf < key || (kf == key && (uint32_t)f < lane)) rank++;
-            }
-        }
-        if (keep && rank < MFA_REGION_MAX) tab[1 + rank] = (uint64_t)lo | ((uint64_t)hi << 24) | ((uint64_t)q << 48);
-        if (lane == 0) tab[0] = (uint64_t)(total < MFA_REGION_MAX ? total : MFA_REGION_MAX) |
-                                ((total > MFA_REGION_MAX || st.ncand > 64u) ? MFA_REGION_OVERFLOW : 0ull);
+        if (MODE == 1) { if (lane == 0) tab[0] = sc.st.ncand; continue; }
+        finish_string(sc, lane, g, bytes, total16, tab);
     }
 }
 
 int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream) {
     if (n == 0) return MFA_OK;
-    uint64_t blocks = (n + 3) / 4;
-    const uint64_t cap = (uint64_t)(n_cus > 0 ? n_cus : 256) * 8u * 64u;      // beyond this waves take several strings each
-    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
     const char* em = getenv("MFA_REGION_MODE");                   // development knobs
-    const char* ep = getenv("MFA_REGION_PF");
-    const char* ed = getenv("MFA_REGION_DPP");
-    const int mode = em ? atoi(em) : 0, pf = ep ? atoi(ep) : 1, dpp = ed ? atoi(ed) : 0;
-    if (const char* ec = getenv("MFA_REGION_CAP")) { const uint64_t c = (uint64_t)atoll(ec); if (c > 0 && blocks > c) blocks = c; }
-    const char* eg = getenv("MFA_REGION_GRP");
-    const int grp = eg ? atoi(eg) : 0;
-#define GO(M, P, D, G) hipLaunchKernelGGL((region_scan_kernel<M, P, D, G>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_bytes, d_offsets, n, d_table)
-    if (mode == 1) { if (grp == 4) GO(1, 1, true, 4); else if (grp == 2) GO(1, 1, true, 2); else if (dpp) GO(1, 2, true, 0); else GO(1, 1, false, 0); }
-    else if (grp == 4) GO(0, 1, true, 4);
-    else if (grp == 2) GO(0, 1, true, 2);
-    else if (grp == 8) GO(0, 1, true, 8);
-    else if (dpp) GO(0, 2, true, 0);
-    else GO(0, 1, false, 0);
-#undef GO
+    const int mode = em ? atoi(em) : 0;
+    const uint64_t cus = (uint64_t)(n_cus > 0 ? n_cus : 256);
+    uint64_t blocks = (n + 3) / 4;
+    const uint64_t cap = cus * 8u * 64u;                          // beyond this waves take several strings each
+    if (blocks > cap) blocks = cap;
+    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, d_bytes, d_offsets, n, d_table);
+    else hipLaunchKernelGGL((region_scan_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, s, d_bytes, d_offsets, n, d_table);
     HIP_TRY(hipGetLastError());
     return MFA_OK;
 }
