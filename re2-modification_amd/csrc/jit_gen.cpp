@@ -408,7 +408,7 @@ struct Gen {
         const bool huge = jit_slot_registers(g) > 272;
         const uint32_t lanes = huge ? huge_lanes((uint32_t)words.size()) : 64u;
         const uint32_t stride = huge ? lanes + 1 : 64u;
-        const bool lds_next = huge || words.size() > 24;
+        const bool lds_next = huge || (int)words.size() > knob("MFA_GEN_LDS_NEXT_MIN", 24);
         o << "#define LANES " << lanes << "u\n#define PSTRIDE " << stride << "u\n#define HUGE " << (huge ? 1 : 0) << "\n";
         o << "#define NEXT_IN_LDS " << (lds_next ? 1 : 0) << "\n";
         // LDS-resident words: [word][v|d][column], one bank per column

@@ -421,7 +421,8 @@ def test_more_than_four_cells(regex, tmp_path, monkeypatch):
         parts = ["a" * rng.randint(0, 3), "b" * rng.randint(0, 3), "c" * rng.randint(0, 3), "a" * rng.randint(0, 3), "b" * rng.randint(0, 3)]
         s = "".join(parts) + "".join(reversed(parts)) if rng.random() < 0.5 else "".join(rng.choice("abc") for _ in range(rng.randint(0, 24)))
         strings.append(s.encode())
-    strings += [b"abcaabbccabc" + b"cbccbbaacba"[::-1], b"abc" + b"a" * 40 + b"b" * 30 + b"c" * 20 + b"ab" + b"c" * 20 + b"ba" + b"c" * 20 + b"b" * 30 + b"a" * 40 + b"cba"]
+    strings += [b"abcaabbccabc" + b"cbccbbaacba"[::-1], b"abc" + b"a" * 40 + b"b" * 30 + b"c" * 20 + b"ab" + b"c" * 25 + b"c" * 25 + b"ba" + b"c" * 20 + b"b" * 30 + b"a" * 40 + b"cba",
+                b"abc" + b"ab" + b"ba" + b"cba", b"abcaabbccabcccbaccbbaacba"]
     want = oracle_lib.OracleImage(blob).match(strings)
     for mode in ("generic", "specialised"):
         monkeypatch.setenv("MFA_JIT", "0" if mode == "generic" else "1")
@@ -443,3 +444,26 @@ def test_large_tabulated_automaton(tmp_path):
     want = oracle_lib.OracleImage(blob).match(strings)
     got = gpu_match(img, strings)
     assert np.array_equal(got, want) and 0 < want.sum() < len(strings)
+
+
+@pytest.mark.parametrize("ex", [3, 6, 8])
+def test_full_length_reversed_strings(ex):
+    """BASELINE configs[4] at its real size: the reversed automata (`-reverse`, is_reversed = 1) of the nondeterministic examples on
+    pump-only strings (full walk) and pump + suffix strings (early exit) of pump size 64 KiB, 40 000 and 20 000 with a damaged
+    byte, against the CPU restatement."""
+    from mfa_amd import corpus
+    regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+    rng = np.random.default_rng(170 + ex)
+    a = (prefix + corpus.pumped_string(65536, pump)).encode()
+    b = (prefix + corpus.pumped_string(65536, pump) + suffix).encode()
+    c = (prefix + corpus.pumped_string(40000, pump)).encode()
+    d = bytearray((prefix + corpus.pumped_string(20000, pump) + suffix).encode())
+    d[int(rng.integers(100, len(d) - 100))] = ord("b") if d[5000] != ord("b") else ord("a")
+    e = bytearray(a[:30000])
+    e[int(rng.integers(1000, 29000))] = ord("c")
+    strings = [a, b, c, bytes(d), bytes(e)]
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex%d_reverse" % ex))
+    assert image.blob_info(blob)["reversed"] == 1
+    want = oracle_lib.OracleImage(blob).match(strings)
+    got = gpu_match(capi.Image(blob), strings)
+    assert list(got) == list(want)
