@@ -230,6 +230,11 @@ def secondary_config3(device, capi, n_strings=1 << 17, length=65536):
     res = torch.empty(n_strings, dtype=torch.uint8, device=device)
     t, tr = _timed(img, flat, off, res, device)
     nbytes = n_strings * length
+    # the region pass stops reading a string once its table is full (64 candidates: text made of hundreds of medium runs, here the
+    # a/b noise strings): those strings' bytes are only partly touched
+    tab = capi.region_scan(flat, off)
+    cut = int(((tab[:, 0] & capi.REGION_OVERFLOW) != 0).sum().item())
+    del tab
     # a^L is accepted (SURVEY section 8c anchors: aa, aaa, aaaa, aaaaaaaa -> 1), every string containing a b is not
     ok = bool(res[1::4].all().item()) and not bool(res[0::4].any().item()) and not bool(res[2::4].any().item())
     import oracle_lib
@@ -240,8 +245,11 @@ def secondary_config3(device, capi, n_strings=1 << 17, length=65536):
     return {"workload": "configs[2]: ({a*}:1&1)*, %d strings of exactly %d bytes, 4-way attack mix" % (n_strings, length),
             "kernel": "region_scan_kernel + mfa_jit_kernel", "region_ms": tr, "walk_ms": t, "GB/s": nbytes / ((t + tr) * 1e-3) / 1e9,
             # the walk stops at the first empty state set (mfa.cpp:224-225), but the region pass has read every byte by then
-            "touched_bytes": nbytes, "touched_by": "region_scan_kernel reads every byte of every string; the walk reads only the bytes of the steps it executes",
-            "frac_of_hbm_peak_on_touched_bytes": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "touched_bytes": {"at_least": nbytes - cut * length, "at_most": nbytes},
+            "touched_by": "region_scan_kernel reads every byte of every string except %d strings (%.1f %%) whose region table filled up, which it "
+                          "stops reading there; the walk reads only the bytes of the steps it executes" % (cut, 100.0 * cut / n_strings),
+            "frac_of_hbm_peak_on_touched_bytes": {"at_least": (nbytes - cut * length) / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                                  "at_most": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "region_pass_GB/s": nbytes / (tr * 1e-3) / 1e9 if tr > 0 else None,
             "results_as_expected": ok, "parity_oracle_sample": _oracle_sample(blob, short, got)}
 

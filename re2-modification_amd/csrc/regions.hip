@@ -315,7 +315,7 @@ __device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo
     }
     if (keep && rank < MFA_REGION_MAX) tab[1 + rank] = (uint64_t)lo | ((uint64_t)hi << 24) | ((uint64_t)q << 48);
     if (lane == 0) tab[0] = (uint64_t)(total < MFA_REGION_MAX ? total : MFA_REGION_MAX) |
-                            ((total > MFA_REGION_MAX || st.ncand > 64u) ? MFA_REGION_OVERFLOW : 0ull);
+                            ((total > MFA_REGION_MAX || st.ncand >= 64u) ? MFA_REGION_OVERFLOW : 0ull);
 }
 
 // ---- kernels ---------------------------------------------------------------------------------------------------
@@ -346,6 +346,9 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
             load_row(bytes, g, ymax, row + 1, lane, nx, ny);            // the next row is on its way while this one is looked at
             scan_row(sc, lane, g, row, x, y);
             x = nx; y = ny;
+            // More candidates than lanes to hold them (text made of hundreds of medium runs): the table would carry the overflow
+            // flag whatever comes, and the walk cannot skip much of such a string anyway -- the rest of it is not read.
+            if (sc.st.ncand >= 64u) break;
         }
         if (MODE == 1) { if (lane == 0) tab[0] = sc.st.ncand; continue; }
         finish_string(sc, lane, g, bytes, total16, tab);
