@@ -236,14 +236,14 @@ def secondary_config3(device, capi, n_strings=1 << 17, length=65536):
     cut = int(((tab[:, 0] & capi.REGION_OVERFLOW) != 0).sum().item())
     del tab
     # a^L is accepted (SURVEY section 8c anchors: aa, aaa, aaaa, aaaaaaaa -> 1), every string containing a b is not
-    ok = bool(res[1::4].all().item()) and not bool(res[0::4].any().item()) and not bool(res[2::4].any().item())
+    ok = bool(res[1::4].all().item()) and not bool(res[0::4].any().item()) and not bool(res[2::4].any().item()) and not bool(res[3::4].any().item())
     import oracle_lib
     data_s, off_s = oracle_lib.pack(short)
     import numpy as np
     d_b = torch.zeros(len(data_s) + 64, dtype=torch.uint8, device=device); d_b[:len(data_s)] = torch.from_numpy(data_s.copy())
     got = img.match_tensors(d_b, torch.from_numpy(off_s.astype(np.int64)).to(device)).cpu().numpy()
     return {"workload": "configs[2]: ({a*}:1&1)*, %d strings of exactly %d bytes, 4-way attack mix" % (n_strings, length),
-            "kernel": "region_scan_kernel + mfa_jit_kernel", "region_ms": tr, "walk_ms": t, "GB/s": nbytes / ((t + tr) * 1e-3) / 1e9,
+            "kernel": "region_scan_kernel + mfa_jit_kernel", "region_ms": tr, "walk_ms": t, "GB/s_on_sum_of_lengths": nbytes / ((t + tr) * 1e-3) / 1e9,
             # the walk stops at the first empty state set (mfa.cpp:224-225), but the region pass has read every byte by then
             "touched_bytes": {"at_least": nbytes - cut * length, "at_most": nbytes},
             "touched_by": "region_scan_kernel reads every byte of every string except %d strings (%.1f %%) whose region table filled up, which it "
