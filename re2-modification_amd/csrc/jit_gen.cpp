@@ -50,8 +50,11 @@ const char* kPrelude =
 // a dual step and its probe need (current and next set with directions, three probe images), plus one column
 // that the idle lanes scribble on.  The idle lanes still take part in the cooperative scans.
 static uint32_t huge_lanes(uint32_t n_words) {
-    for (uint32_t lanes : {32u, 16u, 8u})
-        if ((size_t)7 * n_words * (lanes + 1) * 4 <= 156 * 1024) return lanes;
+    // per column: current and next set with directions (the probe images live in the wave's scratch area, which only the
+    // sparse loops of the main loop touch), the lane's Input and its region-table cache; 1 KiB for everything else
+    const size_t column = (size_t)4 * n_words * 4 + 160 /* >= sizeof(Input), asserted in the generated source */ + 8 * 2 /* MFA_RT_CACHED */;
+    for (uint32_t lanes = 64; lanes >= 8; lanes -= 2)          // even: the stride lanes + 1 is odd
+        if (column * (lanes + 1) + 1024 <= 160 * 1024) return lanes;
     return 0;
 }
 
@@ -67,6 +70,7 @@ struct Gen {
     int K;
     bool rev;
     int tmp = 0;
+    bool sparse = false;      // huge automata: the step only touches slots that the wave's occupancy mask marks (emit_step_chunked)
 
     explicit Gen(const HostImage& img) : g(img), K((int)(img.h.n_cells ? img.h.n_cells : 1)), rev(img.h.is_reversed != 0) {}
 
@@ -103,11 +107,48 @@ struct Gen {
         return dyn.empty() ? "false" : "(" + dyn + ")";
     }
 
+    // The outcome of a cell read on the lanes in `rd`: `ok`.  Run extents and byte-wise comparisons are done by the whole wave, one
+    // lane's at a time.
+    void emit_read_check(const std::string& ind, const std::string& rd, const std::string& vs, const std::string& vl, const std::string& vf,
+                         const std::string& ok, const std::string& id) {
+                o << ind << "    {                                                  // run extent for one-byte-repeated values: found by the whole wave\n";
+                o << ind << "      bool nr = " << rd << " && uni_needs_run(in, val(i), ch, val(" << vl << "), " << vf << ");\n";
+                o << ind << "      if (nr && in.rt != nullptr) {                      // the pre-pass knows every long run\n"
+                  << ind << "        uint32_t rh;\n"
+                  << ind << "        if (rt_run<REV>(in, val(i), rh) || run_end_bounded<REV>(in, val(i), ch, 192u, rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }\n"
+                  << ind << "      }\n";
+                o << ind << "      for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {\n";
+                o << ind << "        const int L = __builtin_ctzll(sb);\n";
+                o << ind << "        const uint32_t r = coop_run_end<REV>(in.bytes, ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L),\n";
+                o << ind << "                                            __shfl(in.len, L), __shfl(val(i), L), threadIdx.x & 63u);\n";
+                // a run is a periodic region too: remember it as one, so that the main loop's look does not measure it again
+                // (unless a region that reaches at least as far is already known -- a probe may be relying on it)
+                o << ind << "        if ((threadIdx.x & 63u) == (uint32_t)L) {\n"
+                  << ind << "          in.run_lo = val(i); in.run_hi = r; in.run_ch = ch;\n"
+                  << ind << "          if (!(in.per_q != 0u && in.per_lo <= val(i) && val(i) < in.per_hi && in.per_hi >= r)) { in.per_lo = val(i); in.per_hi = r; in.per_q = 1u; }\n"
+                  << ind << "        }\n";
+                o << ind << "      }\n";
+                o << ind << "    }\n";
+                o << ind << "    bool " << ok << " = false, cmp" << id << " = false;\n";
+                o << ind << "    if (" << rd << ") " << ok << " = read_pre_u<REV, U>(in, i, ch, " << vs << ", " << vl << ", " << vf << ", TB, cmp" << id << ");\n";
+                o << ind << "    for (unsigned long long sb = __ballot(cmp" << id << "); sb; sb &= sb - 1ull) {      // byte-wise comparisons: one lane's at a time, whole wave\n";
+                o << ind << "      const int L = __builtin_ctzll(sb);\n";
+                o << ind << "      const uint32_t ca = val(" << vs << "), cb = val(i), cl = val(" << vl << ");\n";
+                o << ind << "      const uint64_t pa = in.base + (REV ? (uint64_t)(in.len - ca - cl) : (uint64_t)ca), pb = in.base + (REV ? (uint64_t)(in.len - cb - cl) : (uint64_t)cb);\n";
+                o << ind << "      const bool r = coop_mem_equal(in.bytes, ((uint64_t)__shfl((uint32_t)(pa >> 32), L) << 32) | __shfl((uint32_t)pa, L),\n";
+                o << ind << "                                    ((uint64_t)__shfl((uint32_t)(pb >> 32), L) << 32) | __shfl((uint32_t)pb, L), __shfl(cl, L), threadIdx.x & 63u);\n";
+                o << ind << "      if ((threadIdx.x & 63u) == (uint32_t)L) " << ok << " = r;\n";
+                o << ind << "    }\n";
+    }
+
+    bool outline_reads = false;
+
     void insert(uint32_t m, const std::string& pred, const std::string& P, const Sym& t, const std::string& ind) {
         std::string w = "w" + num(tmp++), pv = "p" + num(tmp++);
         o << ind << "{ const U " << pv << " = " << P << ";\n";
         o << ind << "  const bool " << w << " = (" << pred << ") && lt(" << pv << ", U(n.P" << m << "), TB);\n";
         o << ind << "  if (!NextSet<U>::in_lds || __any(" << w << ")) {       // a next set in LDS is only touched when some lane wins\n";
+        if (sparse) o << ind << "  occn" << (m < 64 ? 0 : 1) << " |= 1ull << " << (m & 63) << "; any_next = any_next || " << w << ";\n";
         o << ind << "  n.P" << m << " = sel(" << w << ", " << pv << ", U(n.P" << m << "));\n";
         for (int c = 0; c < K; c++) {
             std::string sfx = num(m) + "_" + num(c);
@@ -182,34 +223,11 @@ struct Gen {
                 o << ind << "    const U " << vs << " = U(" << s.S[d] << "), " << vl << " = U(" << s.L[d] << "); const uint32_t " << vf << " = flagv(U("
                   << s.F[d] << "), TB);\n";
                 o << ind << "    " << s.F[d] << " = sel(" << rd << ", konst<U>(" << vf << " | F_READ), U(" << s.F[d] << "));\n";
-                o << ind << "    {                                                  // run extent for one-byte-repeated values: found by the whole wave\n";
-                o << ind << "      bool nr = " << rd << " && uni_needs_run(in, val(i), ch, val(" << vl << "), " << vf << ");\n";
-                o << ind << "      if (nr && in.rt != nullptr) {                      // the pre-pass knows every long run\n"
-                  << ind << "        uint32_t rh;\n"
-                  << ind << "        if (rt_run<REV>(in, val(i), rh) || run_end_bounded<REV>(in, val(i), ch, 192u, rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }\n"
-                  << ind << "      }\n";
-                o << ind << "      for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {\n";
-                o << ind << "        const int L = __builtin_ctzll(sb);\n";
-                o << ind << "        const uint32_t r = coop_run_end<REV>(in.bytes, ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L),\n";
-                o << ind << "                                            __shfl(in.len, L), __shfl(val(i), L), threadIdx.x & 63u);\n";
-                // a run is a periodic region too: remember it as one, so that the main loop's look does not measure it again
-                // (unless a region that reaches at least as far is already known -- a probe may be relying on it)
-                o << ind << "        if ((threadIdx.x & 63u) == (uint32_t)L) {\n"
-                  << ind << "          in.run_lo = val(i); in.run_hi = r; in.run_ch = ch;\n"
-                  << ind << "          if (!(in.per_q != 0u && in.per_lo <= val(i) && val(i) < in.per_hi && in.per_hi >= r)) { in.per_lo = val(i); in.per_hi = r; in.per_q = 1u; }\n"
-                  << ind << "        }\n";
-                o << ind << "      }\n";
-                o << ind << "    }\n";
-                o << ind << "    bool " << ok << " = false, cmp" << id << " = false;\n";
-                o << ind << "    if (" << rd << ") " << ok << " = read_pre_u<REV, U>(in, i, ch, " << vs << ", " << vl << ", " << vf << ", TB, cmp" << id << ");\n";
-                o << ind << "    for (unsigned long long sb = __ballot(cmp" << id << "); sb; sb &= sb - 1ull) {      // byte-wise comparisons: one lane's at a time, whole wave\n";
-                o << ind << "      const int L = __builtin_ctzll(sb);\n";
-                o << ind << "      const uint32_t ca = val(" << vs << "), cb = val(i), cl = val(" << vl << ");\n";
-                o << ind << "      const uint64_t pa = in.base + (REV ? (uint64_t)(in.len - ca - cl) : (uint64_t)ca), pb = in.base + (REV ? (uint64_t)(in.len - cb - cl) : (uint64_t)cb);\n";
-                o << ind << "      const bool r = coop_mem_equal(in.bytes, ((uint64_t)__shfl((uint32_t)(pa >> 32), L) << 32) | __shfl((uint32_t)pa, L),\n";
-                o << ind << "                                    ((uint64_t)__shfl((uint32_t)(pb >> 32), L) << 32) | __shfl((uint32_t)pb, L), __shfl(cl, L), threadIdx.x & 63u);\n";
-                o << ind << "      if ((threadIdx.x & 63u) == (uint32_t)L) " << ok << " = r;\n";
-                o << ind << "    }\n";
+                if (outline_reads) {
+                    // huge automata: the whole check is one out-of-line function (a read site inlined is ~10 KB of code, eight of them per node)
+                    o << ind << "    bool " << ok << " = false;\n"
+                      << ind << "    { const ReadOut ro = huge_cell_read<U>(i, ch, " << vs << ", " << vl << ", " << vf << ", " << rd << ", TB); " << ok << " = ro.ok; TB = ro.TB; }\n";
+                } else emit_read_check(ind, rd, vs, vl, vf, ok, id);
                 o << ind << "    if (__any(" << ok << ")) {\n";
                 apply_actions(t, e.actions, ok, "i", vl, "((" + vf + " & F_UNI) != 0u)", "((" + vf + " >> 8) & 0xffu)", ind + "      ");
                 insert(e.target, ok, "mkp(add(i, " + vl + "), " + fname(t) + ")", t, ind + "      ");
@@ -289,6 +307,19 @@ struct Gen {
         for (uint32_t k = 0; k < deg(n); k++) has_eps = has_eps || eps(edge(n, k));
         if (has_eps) o << "  accept = accept || (live" << n << " && eq(pos" << n << ", len, TB));\n";
         std::string q = qualifies(n, s);
+        if (sparse) {
+            // the next set is all-empty when a step starts (huge_commit leaves it so): only a state that waits is written, with its cells
+            if (q == "false") return;
+            o << "  { const bool carry = wait" << n << " && " << q << ";\n    if (__any(carry)) {\n      occn" << (n < 64 ? 0 : 1) << " |= 1ull << " << (n & 63)
+              << "; any_next = any_next || carry;\n      assign_if(n.P" << n << ", carry, U(c.P" << n << "));";
+            for (int c = 0; c < K; c++) {
+                std::string sfx = num(n) + "_" + num(c);
+                o << " assign_if(n.S" << sfx << ", carry, U(c.S" << sfx << ")); assign_if(n.L" << sfx << ", carry, U(c.L" << sfx << ")); assign_if(n.F" << sfx
+                  << ", carry, U(c.F" << sfx << "));";
+            }
+            o << "\n    }\n  }\n";
+            return;
+        }
         o << "  n.P" << n << " = sel(wait" << n << " && " << q << ", U(c.P" << n << "), konst<U>(MFA_EMPTY));";
         for (int c = 0; c < K; c++) {
             std::string sfx = num(n) + "_" + num(c);
@@ -334,8 +365,8 @@ struct Gen {
         const uint32_t N = g.h.n_nodes;
         o << "template <class U>\n__device__ __forceinline__ void mfa_step(SlotSet<U>& c, Input& in, const U i, const U len, const uint32_t ch,\n"
              "                                         const bool final_pass, bool& accept, bool& any_next, tb_t& TB, uint32_t* cur_mem,\n"
-             "                                         uint32_t* nxt_mem, const bool active) {\n";
-        o << "  NextSet<U> n(nxt_mem);\n  (void)cur_mem;\n";
+             "                                         uint32_t* nxt_mem, const bool active, unsigned long long& occ0, unsigned long long& occ1) {\n";
+        o << "  NextSet<U> n(nxt_mem);\n  (void)cur_mem; (void)occ0; (void)occ1;\n";
         for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) emit_classify(n);
         for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) emit_phase_a(n);
         for (uint32_t n = 0; n < N; n++) if (!is_finish(n) && deg(n) != 0) emit_phase_b(n);
@@ -347,57 +378,168 @@ struct Gen {
     // Huge automata: the slot sets are in LDS anyway, so the step is cut into out-of-line functions of a few nodes
     // each (one inlined function of several hundred edges takes the compiler tens of minutes).  Phase order is kept:
     // all of A, then B in node order, then C in node order.
+    // Huge automata.  Two things keep a step from costing what 76 slots cost when two to eight are occupied:
+    //  * occ0/occ1 (wave-uniform, kept by the main loop): bit n set = slot n may be occupied in some lane.  Everything a step does
+    //    for a node sits behind a scalar test of its bit -- an empty slot costs a compare and a branch, no LDS access;
+    //  * the next set is all-empty when a step starts.  Carried and inserted states set their node's bit in occn; huge_commit then
+    //    moves exactly those nodes' words from the next set to the current one (per lane only where the slot is really occupied, so
+    //    that the cell words of a lane's empty slots stay what they were: the probes compare whole slot sets), empties them in the
+    //    next set again, and empties the current slots that were vacated.
     void emit_step_chunked() {
         const uint32_t N = g.h.n_nodes;
-        const char* sig = "(uint32_t* cur_mem, uint32_t* nxt_mem, Input& in_arg, const U i, const U len, const uint32_t ch, const bool final_pass,\n"
-                          "    bool& accept_arg, bool& any_next_arg, tb_t& TB_arg, const bool active)";
+        sparse = knob("MFA_GEN_SPARSE", 1) != 0;
+        // What a step works on besides the slot sets travels by value, in and out: by reference it went through the caller's
+        // stack, a dozen FLAT accesses with their full latency per call and twenty calls a step.
+        const char* sig = "(const StepIO io, const U i, const U len, const uint32_t ch, const bool final_pass, const bool active,\n"
+                          "    unsigned long long occ0_arg, unsigned long long occ1_arg)";
         // The slot sets and the input state are reached through the file-scope LDS arrays, not through the pointer
         // and reference parameters: only then does the compiler know the address space and emit DS instructions
         // (through generic pointers every slot access was a FLAT instruction: 4 200 of them per step).
         const char* pre = "  const uint32_t hl_lane = threadIdx.x & 63u, hl_col = hl_lane < LANES ? hl_lane : LANES;\n"
-                          "  uint32_t* const cm = huge_lds + hl_col; uint32_t* const nm = cm + 2 * N_WORDS * PSTRIDE; (void)cur_mem; (void)nxt_mem;\n"
-                          "  Input& in = huge_in[hl_col]; (void)in_arg;\n"
+                          "  uint32_t* const cm = huge_lds + hl_col; uint32_t* const nm = cm + 2 * N_WORDS * PSTRIDE;\n"
+                          "  Input& in = huge_in[hl_col];\n"
                           "  SlotSet<U> c(cm); NextSet<U> n(nm); (void)c; (void)n; (void)in; (void)ch;\n"
-                          "  bool accept = accept_arg, any_next = any_next_arg; tb_t TB = TB_arg;      // worked on in registers, written back at the end\n";
-        const char* post = "  accept_arg = accept; any_next_arg = any_next; TB_arg = TB;\n}\n\n";
-        std::vector<std::string> calls;
+                          "  bool accept = io.accept, any_next = io.any_next; tb_t TB = io.TB;\n"
+                          "  const unsigned long long occ0 = uniform64(occ0_arg), occ1 = uniform64(occ1_arg); (void)occ0; (void)occ1;\n"
+                          "  unsigned long long occn0 = uniform64(io.occn0), occn1 = uniform64(io.occn1);\n";
+        const char* post = "  return StepIO{accept, any_next, TB, occn0, occn1};\n}\n\n";
+        outline_reads = true;
+        o << "struct ReadOut { bool ok; tb_t TB; };\n"
+             "template <class U>\n__device__ __attribute__((noinline)) ReadOut huge_cell_read(const U i, const uint32_t ch, const U vs, const U vl, const uint32_t vf, const bool rd, tb_t TB) {\n"
+             "  const uint32_t hl_lane = threadIdx.x & 63u; Input& in = huge_in[hl_lane < LANES ? hl_lane : LANES];\n";
+        emit_read_check("", "rd", "vs", "vl", "vf", "ok", "_r");
+        o << "  return ReadOut{ok, TB};\n}\n\n";
+        o << "struct StepIO { bool accept, any_next; tb_t TB; unsigned long long occn0, occn1; };\n"
+             "__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {\n"
+             "  return ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(v >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)v);\n}\n";
+        // Sparse mode: one function per node and phase, called only when the node's bit is set.  A step then runs through the
+        // code of the occupied nodes and a compact row of bit tests, not through 700 KB of guarded blocks: with one wave per CU
+        // every skipped block was an instruction-cache miss (~230 per step, 80-150 k cycles a step on ex. 8 -reverse).
+        std::vector<std::string> calls, call_guard;
+        uint64_t fn_mask[2] = {0, 0};
         auto begin_fn = [&](const std::string& name) {
-            o << "template <class U>\n__device__ __attribute__((noinline)) void " << name << sig << " {\n" << pre;
+            o << "template <class U>\n__device__ __attribute__((noinline)) StepIO " << name << sig << " {\n" << pre;
             calls.push_back(name);
+            fn_mask[0] = fn_mask[1] = 0;
         };
-        begin_fn("step_a");
-        for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) { emit_classify(n); emit_phase_a(n); }
-        o << post;
+        auto end_fn = [&]() {
+            o << post;
+            std::string gd;
+            if (sparse) {
+                char buf[96];
+                snprintf(buf, sizeof buf, "((occ0 & 0x%llxull) | (occ1 & 0x%llxull)) != 0ull", (unsigned long long)fn_mask[0], (unsigned long long)fn_mask[1]);
+                gd = buf;
+            }
+            call_guard.push_back(gd);
+        };
+        auto node_in_fn = [&](uint32_t n) { fn_mask[n >> 6] |= 1ull << (n & 63); };
+        const uint32_t chunk_budget = sparse ? 1 : 24;
+        if (sparse) {
+            for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) { begin_fn("step_a" + num(n)); node_in_fn(n); emit_classify(n); emit_phase_a(n); end_fn(); }
+        } else {
+            begin_fn("step_a");
+            for (uint32_t n = 0; n < N; n++) if (!is_finish(n)) { emit_classify(n); emit_phase_a(n); }
+            end_fn();
+        }
         int chunk = 0;
         uint32_t budget = 0;
         bool open = false;
         for (uint32_t n = 0; n < N; n++) {
             if (is_finish(n) || deg(n) == 0) continue;
             if (!open) { begin_fn("step_b" + num(chunk++)); open = true; budget = 0; }
+            node_in_fn(n);
             emit_classify(n);
             emit_phase_b(n);
             budget += deg(n);
-            if (budget >= 24) { o << post; open = false; }
+            if (budget >= chunk_budget) { end_fn(); open = false; }
         }
-        if (open) { o << post; open = false; }
+        if (open) { end_fn(); open = false; }
         chunk = 0;
         for (uint32_t n = 0; n < N; n++) {
             if (is_finish(n) || !has_phase_c(n)) continue;
             if (!open) { begin_fn("step_c" + num(chunk++)); open = true; budget = 0; }
+            node_in_fn(n);
             emit_classify(n);
             emit_phase_c(n);
             budget += deg(n);
-            if (budget >= 24) { o << post; open = false; }
+            if (budget >= chunk_budget) { end_fn(); open = false; }
         }
-        if (open) { o << post; open = false; }
-        begin_fn("step_end");
-        emit_end();
-        o << post;
+        if (open) { end_fn(); open = false; }
+        if (!sparse) {
+            begin_fn("step_end");
+            emit_end();
+            end_fn();
+        } else {
+            // words of node n start at word (n minus the finish node if it comes before) * (1 + 3 K): P, then S, L, F per cell
+            o << "template <class U> struct HugeWord;\n"
+                 "template <> struct HugeWord<uint32_t> { static constexpr bool dual = false; };\n"
+                 "template <> struct HugeWord<Dual> { static constexpr bool dual = true; };\n";
+            o << "template <class U>\n__device__ __attribute__((noinline)) void huge_commit(unsigned long long occ0_arg, unsigned long long occ1_arg, unsigned long long occn0_arg,\n"
+                 "                                                          unsigned long long occn1_arg) {\n"
+                 "  const uint32_t hl_lane = threadIdx.x & 63u, hl_col = hl_lane < LANES ? hl_lane : LANES;\n"
+                 "  uint32_t* const cm = huge_lds + hl_col; uint32_t* const nm = cm + 2 * N_WORDS * PSTRIDE;\n"
+                 "  const unsigned long long occ[2] = {uniform64(occ0_arg), uniform64(occ1_arg)}, occn[2] = {uniform64(occn0_arg), uniform64(occn1_arg)};\n"
+                 "  constexpr uint32_t WPN = " << (1 + 3 * K) << "u, FIN = " << g.h.finish << "u;\n"
+                 "  for (int h = 0; h < 2; h++)\n"
+                 "    for (unsigned long long m = occ[h] | occn[h]; m; m &= m - 1ull) {\n"
+                 "      const uint32_t node = 64u * (uint32_t)h + (uint32_t)__builtin_ctzll(m);\n"
+                 "      const uint32_t k0 = (node - (node > FIN ? 1u : 0u)) * WPN;\n"
+                 "      uint32_t* const cw = cm + 2u * k0 * PSTRIDE; uint32_t* const nw = nm + 2u * k0 * PSTRIDE;\n"
+                 "      if (!((occn[h] >> (node & 63u)) & 1ull)) { cw[0] = MFA_EMPTY; if (HugeWord<U>::dual) cw[PSTRIDE] = 0u; continue; }      // vacated everywhere\n"
+                 "      const uint32_t p = nw[0];\n"
+                 "      cw[0] = p; if (HugeWord<U>::dual) cw[PSTRIDE] = nw[PSTRIDE];\n"
+                 "      if (p != MFA_EMPTY) {\n"
+                 "        for (uint32_t j = 1; j < WPN; j++) { cw[2u * j * PSTRIDE] = nw[2u * j * PSTRIDE]; if (HugeWord<U>::dual) cw[(2u * j + 1u) * PSTRIDE] = nw[(2u * j + 1u) * PSTRIDE]; }\n"
+                 "      } else if (HugeWord<U>::dual && !((occ[h] >> (node & 63u)) & 1ull)) {\n"
+                 "        for (uint32_t j = 1; j < WPN; j++) cw[(2u * j + 1u) * PSTRIDE] = 0u;      // a node joining in the middle of a dual period: its cells rest in the lanes where it stays empty\n"
+                 "      }\n"
+                 "      nw[0] = MFA_EMPTY; nw[PSTRIDE] = 0u;\n"
+                 "    }\n}\n\n";
+        }
         o << "template <class U>\n__device__ __forceinline__ void mfa_step(SlotSet<U>&, Input& in, const U i, const U len, const uint32_t ch,\n"
              "                                         const bool final_pass, bool& accept, bool& any_next, tb_t& TB, uint32_t* cur_mem,\n"
-             "                                         uint32_t* nxt_mem, const bool active) {\n";
-        for (const auto& f : calls) o << "  " << f << "<U>(cur_mem, nxt_mem, in, i, len, ch, final_pass, accept, any_next, TB, active);\n";
+             "                                         uint32_t* nxt_mem, const bool active, unsigned long long& occ0, unsigned long long& occ1) {\n";
+        if (sparse) o << "  any_next = false;\n";
+        o << "  StepIO io{accept, any_next, TB, 0ull, 0ull};\n  (void)in; (void)cur_mem; (void)nxt_mem;\n";
+        for (size_t f = 0; f < calls.size(); f++)
+            o << "  " << (call_guard[f].empty() ? "" : "if (" + call_guard[f] + ") ") << "io = " << calls[f]
+              << "<U>(io, i, len, ch, final_pass, active, occ0, occ1);\n";
+        o << "  accept = io.accept; any_next = io.any_next; TB = io.TB;\n";
+        if (sparse) o << "  huge_commit<U>(occ0, occ1, io.occn0, io.occn1);\n  occ0 = io.occn0; occ1 = io.occn1;\n";
         o << "}\n\n";
+    }
+
+    // One statement per slot word.  In `body`, K_ is the word's index, CW_ / DW_ the word of the current set as a plain value
+    // and as a dual number, ISP_ whether it is a P word.  Huge automata in sparse mode loop at run time over the words of
+    // the nodes in pocc0/pocc1 (every node occupied in some lane at some step since the running probes began: all other
+    // words have not moved and nobody reads them); everything else is unrolled over all words.
+    void each_word(const std::vector<std::string>& words, bool loop, const std::string& ind, const std::string& body) {
+        auto subst = [&](const std::string& k, const std::string& cw, const std::string& dw, const std::string& isp) {
+            std::string r;
+            for (size_t a = 0; a < body.size();) {
+                auto take = [&](const char* tok, const std::string& with) {
+                    const size_t n = std::char_traits<char>::length(tok);
+                    if (body.compare(a, n, tok) == 0) { r += with; a += n; return true; }
+                    return false;
+                };
+                if (take("K_", k) || take("CW_", cw) || take("DW_", dw) || take("ISP_", isp)) continue;
+                r += body[a++];
+            }
+            return r;
+        };
+        if (!loop) {
+            for (size_t k = 0; k < words.size(); k++)
+                o << ind << "{ " << subst(num((uint32_t)k), "c." + words[k], "dc." + words[k], words[k][0] == 'P' ? "true" : "false") << " }\n";
+            return;
+        }
+        o << ind << "for (int h_ = 0; h_ < 2; h_++)\n"
+          << ind << "  for (unsigned long long m_ = uniform64(h_ ? pocc1 : pocc0) & ~(h_ == " << (g.h.finish < 64 ? 0 : 1) << " ? 1ull << " << (g.h.finish & 63) << " : 0ull); m_; m_ &= m_ - 1ull) {\n"
+          << ind << "    const uint32_t node_ = 64u * (uint32_t)h_ + (uint32_t)__builtin_ctzll(m_);\n"
+          << ind << "    const uint32_t k0_ = (node_ - (node_ > " << g.h.finish << "u ? 1u : 0u)) * " << (1 + 3 * K) << "u;\n"
+          << ind << "    for (uint32_t j = 0; j < " << (1 + 3 * K) << "u; j++) {\n"
+          << ind << "      const uint32_t k = k0_ + j; LdsPlain cw{cur_mem + 2u * k * PSTRIDE}; LdsDual dw{cur_mem + 2u * k * PSTRIDE}; (void)cw; (void)dw;\n"
+          << ind << "      " << subst("k", "cw", "dw", "(j == 0u)") << "\n"
+          << ind << "    }\n" << ind << "  }\n";
     }
 
     std::string run() {
@@ -460,8 +602,9 @@ struct Gen {
             o << " {}\n};\n";
         } else reg_struct("NextSet", "Dual");
         o << "\n";
-        if (huge) o << "__shared__ uint32_t huge_lds[7 * N_WORDS * PSTRIDE];      // cur, next (v and d each), SA, SB, SD\n__shared__ Input huge_in[LANES + 1];\n\n";
+        if (huge) o << "__shared__ uint32_t huge_lds[4 * N_WORDS * PSTRIDE];      // cur, next (v and d each)\n__shared__ Input huge_in[LANES + 1];\nstatic_assert(sizeof(Input) <= 160 && MFA_RT_CACHED == 2u, \"huge_lanes() budget\");\n\n";
         if (huge) emit_step_chunked(); else emit_step();
+        const bool wl = huge && sparse;      // probe bookkeeping loops over occupied nodes only (each_word)
         // ---- kernel
         // small automata: ask for two waves per SIMD (<= 128 VGPRs); the plain step needs far fewer, only the dual
         // step is register hungry and may then spill a little -- it is rare
@@ -482,15 +625,9 @@ struct Gen {
              "#else\n  uint32_t* const cur_mem = nullptr;\n  uint32_t* const nxt_mem = nullptr;\n#endif\n";
         o << "  // probe storage of this wave, [array][word][column]: SB = slots at probe start, from the dual period on the slots at its\n"
              "  // start; SA = the direction d measured over the first period; SD = direction carried between dual steps\n";
-        // small automata keep it in LDS, larger ones in an L2-resident scratch buffer
+        // small automata keep it in LDS, larger ones in an L2-resident scratch buffer (huge ones: LDS is what limits their lanes)
         const bool probe_lds = words.size() <= 68;
-        if (huge) {
-            o << "  uint32_t* const SAm = nxt_mem + 2 * N_WORDS * PSTRIDE;\n  uint32_t* const SBm = SAm + N_WORDS * PSTRIDE;\n"
-                 "  uint32_t* const SDm = SBm + N_WORDS * PSTRIDE;\n  (void)scratch;\n"
-                 "#define SA_RD(k) ((int32_t)SAm[(k) * PSTRIDE])\n#define SA_WR(k, v) (SAm[(k) * PSTRIDE] = (uint32_t)(v))\n"
-                 "#define SD_RD(k) ((int32_t)SDm[(k) * PSTRIDE])\n#define SD_WR(k, v) (SDm[(k) * PSTRIDE] = (uint32_t)(v))\n"
-                 "#define SB_RD(k) (SBm[(k) * PSTRIDE])\n#define SB_WR(k, v) (SBm[(k) * PSTRIDE] = (v))\n";
-        } else if (probe_lds) {
+        if (!huge && probe_lds) {
             // directions are small numbers: 16 bits each (a probe whose direction does not fit is abandoned).  SD is only
             // live between two dual steps and the LDS next set only inside one: they share memory.
             // LDS budget for two waves per SIMD: 20 KiB a wave.  The next set comes first, then SA, then SB; what does not
@@ -528,13 +665,17 @@ struct Gen {
              "  bool patient = false;    // a dual period right after the first plain one has failed on this string: wait for two equal movements\n"
              "  unsigned long long st_f_unst = 0, st_f_dual = 0, st_f_room = 0;\n";
         o << "  __shared__ uint64_t rt_cache[MFA_RT_CACHED * (HUGE ? LANES + 1u : 64u)];      // first entries of every lane's region table\n"
-             "  bool first_round = true;\n  uint32_t warm = 0;\n";
+             "  bool first_round = true;\n  uint32_t warm = 0;\n"
+             "  unsigned long long occ0 = 0ull, occ1 = 0ull;      // huge automata: slots that may be occupied in some lane (emit_step_chunked)\n"
+             "  unsigned long long pocc0 = 0ull, pocc1 = 0ull;    // ... in some lane at some step since the running probes began (each_word)\n"
+             "#if HUGE\n  for (uint32_t k = 0; k < N_WORDS; k++) { nxt_mem[2u * k * PSTRIDE] = MFA_EMPTY; nxt_mem[(2u * k + 1u) * PSTRIDE] = 0u; }      // the next set starts empty\n#endif\n";
         o << "  SlotSet<uint32_t> c(cur_mem);\n";
         for (const auto& w : words) o << "  c." << w << " = " << (w[0] == 'P' ? "MFA_EMPTY" : "0u") << ";\n";
         o << "  for (;;) {\n    const unsigned long long tmA = stats ? clock64() : 0;\n";
         o << "    {\n      // hand strings to idle lanes: one atomic per wave, tickets dealt by lane rank\n"
              "      const bool want = !active && !exhausted && lane < LANES;\n      const unsigned long long wb = __ballot(want);\n"
              "      if (wb) {\n        unsigned long long first = 0;\n"
+             "        occ" << (g.h.start < 64 ? 0 : 1) << " |= 1ull << " << (g.h.start & 63) << ";                       // new strings start in the start slot\n"
              "        if (first_round) first = (unsigned long long)blockIdx.x * LANES;      // the first strings of a wave need no ticket\n"
              "        else {\n"
              "          if (lane == (uint32_t)__builtin_ctzll(wb)) first = atomicAdd(counter, (unsigned long long)__builtin_popcountll(wb));\n"
@@ -560,6 +701,7 @@ struct Gen {
         o << "    // does this lane sit at the start of a block that looks periodic?  then find how far the periodic region goes\n"
              "    uint32_t q = 0u;\n"
              "    const bool ep_busy = __any(phase != 0u);      // probes run in epochs: all lanes that probe do it in the same iterations\n"
+             "    if (!ep_busy) { pocc0 = occ0; pocc1 = occ1; } else { pocc0 |= occ0; pocc1 |= occ1; }\n"
              "    if (accel && active && !final_pass && phase == 0u && i >= probe_at && !ep_busy) {\n"
              "#if MFA_INLINE_SCAN\n"
              "      if (in.rt == nullptr) {                       // no table: look at the next 16 bytes (round-1 scheme, A/B runs only)\n"
@@ -600,7 +742,7 @@ struct Gen {
              "    if (q != 0u) {\n"
              "      pp = ep_pp;\n"
              "      if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * pp + 24u) {\n";
-        for (size_t k = 0; k < words.size(); k++) o << "        SB_WR(" << k << ", (uint32_t)c." << words[k] << ");\n";
+        each_word(words, wl, "        ", "SB_WR(K_, (uint32_t)CW_);");
         o << "        phase = 1u; pk = 0u; nper = 0u; stable = false; st_probe++;\n      } else if (in.per_hi - i < 4u * q * mult + 24u) {\n"
              "        probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // region too short to be worth a probe: look again behind it\n"
              "      } else {\n        probe_at = i + 1u;                                       // does not fit this epoch's period: next epoch\n      }\n    }\n";
@@ -608,20 +750,17 @@ struct Gen {
         o << "    if (__any(phase == 2u)) {\n";
         o << "      // dual step: lanes in phase 2 carry the direction saved in SD, the others d = 0 (their TB is ignored)\n";
         o << "      const bool p2 = phase == 2u;\n      SlotSet<Dual> dc(cur_mem);\n      st_dual++;\n";
-        for (size_t k = 0; k < words.size(); k++)
-            o << "      dc." << words[k] << " = Dual{(uint32_t)c." << words[k] << ", p2 ? SD_RD(" << k << ") : 0};\n";
+        each_word(words, wl, "      ", "DW_ = Dual{(uint32_t)CW_, p2 ? SD_RD(K_) : 0};");
         o << "      const Dual di{i, (int32_t)pp}, dlen{len, 0};\n";
         o << "      in.dual_p = p2 ? pp : 0u;\n";
         o << "      (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the periodic region\n";
         o << "      (void)eq(di, dlen, TB);\n";
-        o << "      mfa_step<Dual>(dc, in, di, dlen, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active);\n";
+        o << "      mfa_step<Dual>(dc, in, di, dlen, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active, occ0, occ1);\n      pocc0 |= occ0; pocc1 |= occ1;\n";
         o << "      in.dual_p = 0u;\n";
         o << "      uint32_t skip = 0;\n";
         o << "      if (p2) {\n        tb_min(TBacc, TB.a, TB.b);\n        pk++;\n";
         o << "        if (pk == pp) {\n          const int64_t periods = tb_steps(TBacc);\n          bool same = !accept && any_next && periods > 1 && fits;\n";
-        for (size_t k = 0; k < words.size(); k++)
-            o << "          { const Dual t = dc." << words[k] << "; same = same && t.d == SA_RD(" << k << ") && (int32_t)(t.v - SB_RD(" << k
-              << ")) == SA_RD(" << k << "); }\n";
+        each_word(words, wl, "          ", "const Dual t = DW_; same = same && t.d == SA_RD(K_) && (int32_t)(t.v - SB_RD(K_)) == SA_RD(K_);");
         o << "          if (same) skip = (uint32_t)(periods - 1 < (int64_t)0x00ffffff ? periods - 1 : (int64_t)0x00ffffff);\n";
         o << "          phase = 0u;\n";
         o << "          if (skip) { backoff = 8u; fails = 0u; st_hit++; st_skip += (unsigned long long)skip * pp; }\n";
@@ -634,16 +773,14 @@ struct Gen {
              "          if (nper == 1u && !patient && pp > 2u) patient = true; else mult = mult % 8u + 1u;\n"
              "          if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
              "        } else {\n";
-        for (size_t k = 0; k < words.size(); k++)
-            o << "          { const int32_t d = Dual(dc." << words[k] << ").d; SD_WR(" << k << ", d); fits = fits && d == (int32_t)(int16_t)d; }\n";
+        each_word(words, wl, "          ", "const int32_t d = Dual(DW_).d; SD_WR(K_, d); fits = fits && d == (int32_t)(int16_t)d;");
         o << "        }\n      }\n";
-        for (size_t k = 0; k < words.size(); k++)
-            o << "      { const Dual t = dc." << words[k] << "; c." << words[k] << " = t.v + skip * (uint32_t)t.d; }\n";
+        each_word(words, wl, "      ", "const Dual t = DW_; CW_ = t.v + skip * (uint32_t)t.d;");
         o << "      if (skip) { i += skip * pp; in.blk = ~(uint64_t)0; in.pblk = ~(uint64_t)0; probe_at = i + 1u + pp; }\n";
         o << "      else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);\n";
         o << "      if (phase == 1u) pk++;\n      if (stats) tm_dual += clock64() - tm1;\n";
         o << "    } else {\n";
-        o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active);\n";
+        o << "      mfa_step<uint32_t>(c, in, i, len, ch, final_pass, accept, any_next, TB, cur_mem, nxt_mem, active, occ0, occ1);\n      pocc0 |= occ0; pocc1 |= occ1;\n";
         o << "      if (phase == 1u) pk++;\n      if (stats) tm_plain += clock64() - tm1;\n";
         o << "    }\n";
         // plain periods of a probe: after each one the movement of the slots over the period is compared with the previous
@@ -651,12 +788,8 @@ struct Gen {
         // their period boundaries in the same iteration and go on together: to the dual period when every one of them is
         // ready or has run out of patience (MFA_PROBE_PERIODS plain periods) or of periodic input.
         o << "    if (phase == 1u && pk == pp) {\n      bool eqd = nper != 0u, occ = nper == 0u && !patient && pp > 2u;      // short periods: waiting for a second one costs next to nothing\n      fits = true;\n";
-        for (size_t k = 0; k < words.size(); k++) {
-            o << "      { const uint32_t v = c." << words[k] << ", b = SB_RD(" << k << "); const int32_t d = (int32_t)(v - b); eqd = eqd && d == SA_RD(" << k
-              << "); SA_WR(" << k << ", d); SB_WR(" << k << ", v); fits = fits && d == (int32_t)(int16_t)d;";
-            if (words[k][0] == 'P') o << " occ = occ && (v == MFA_EMPTY) == (b == MFA_EMPTY);";
-            o << " }\n";
-        }
+        each_word(words, wl, "      ", "const uint32_t v = CW_, b = SB_RD(K_); const int32_t d = (int32_t)(v - b); eqd = eqd && d == SA_RD(K_); SA_WR(K_, d); "
+                                     "SB_WR(K_, v); fits = fits && d == (int32_t)(int16_t)d; if (ISP_) occ = occ && (v == MFA_EMPTY) == (b == MFA_EMPTY);");
         // first period: the same slots occupied before and after it is taken as "probably settled already"
         o << "      nper++; pk = 0u; stable = (eqd || occ) && fits;\n    }\n";
         o << "    {\n      const bool at_b = phase == 1u && pk == 0u && nper != 0u;\n"
@@ -664,7 +797,7 @@ struct Gen {
              "        const bool room = in.per_hi >= i + 1u + 2u * pp;          // the dual period and at least one more to skip\n"
              "        if (!__any(at_b && !stable && room && nper < (pp > 2u ? MFA_PROBE_PERIODS : 3u))) {\n"
              "          if (at_b && stable && room) {\n";
-        for (size_t k = 0; k < words.size(); k++) o << "            SD_WR(" << k << ", SA_RD(" << k << "));\n";
+        each_word(words, wl, "            ", "SD_WR(K_, SA_RD(K_));");
         o << "            phase = 2u; TBacc = tb_init();\n"
              "          } else if (at_b) {\n"
              "            phase = 0u;\n"
