@@ -278,7 +278,7 @@ def secondary_64k_all_examples(device, capi, corpus, n_strings=16384):
     return out
 
 
-def secondary_no_regions(device, capi, corpus, n_strings=20000, length=4096):
+def secondary_no_regions(device, capi, corpus, n_strings=262144, length=4096):
     """The per-character step rate as a tracked number: in-language text WITHOUT long periodic regions (nothing for the
     acceleration to skip): example 1's language is every a^n, so a non-periodic in-language text does not exist for it; examples
     6 and 9 accept texts with irregular block lengths.  Also example 1 on its attack strings with MFA_ACCEL=0 semantics (no
@@ -296,13 +296,17 @@ def secondary_no_regions(device, capi, corpus, n_strings=20000, length=4096):
         blob = load_blob("ex%d_plain" % ex)
         img = capi.Image(blob)
         base = [gen() for _ in range(64)]
-        strings = [base[k % 64] for k in range(n_strings)]
-        data, off = oracle_lib.pack(strings)
-        d_b = torch.zeros(len(data) + 64, dtype=torch.uint8, device=device); d_b[:len(data)] = torch.from_numpy(data.copy())
-        d_o = torch.from_numpy(off.astype(np.int64)).to(device)
+        # the batch is the 64 texts repeated (string k = text k % 64), built on the device: enough strings to fill every CU
+        d64, o64 = oracle_lib.pack(base)
+        reps64 = n_strings // 64
+        d_b = torch.cat([torch.from_numpy(d64.copy()).to(device).repeat(reps64), torch.zeros(64, dtype=torch.uint8, device=device)])
+        o64_t = torch.from_numpy(o64.astype(np.int64)).to(device)
+        d_o = torch.cat([(torch.arange(reps64, device=device, dtype=torch.int64)[:, None] * int(o64[-1]) + o64_t[None, :-1]).reshape(-1),
+                         torch.tensor([reps64 * int(o64[-1])], dtype=torch.int64, device=device)])
+        off = d_o
         res = torch.empty(n_strings, dtype=torch.uint8, device=device)
         t, tr = _timed(img, d_b, d_o, res, device, reps=2)
-        nb = int(off[-1])
+        nb = int(off[-1].item())
         short = [s[:1500] for s in base[:8]]
         ds, os_ = oracle_lib.pack(short)
         d_s = torch.zeros(len(ds) + 64, dtype=torch.uint8, device=device); d_s[:len(ds)] = torch.from_numpy(ds.copy())
@@ -314,7 +318,7 @@ def secondary_no_regions(device, capi, corpus, n_strings=20000, length=4096):
         del d_b, d_o, res
     # example 1, attack strings, no table: every step is executed
     img = capi.Image(load_blob("ex1_plain"))
-    n1 = 8192
+    n1 = 262144
     sizes = np.full(n1, 4096, dtype=np.int64)
     flat, off = corpus.device_batch(1, sizes, (np.arange(n1) % 2) == 0, device)
     res = torch.empty(n1, dtype=torch.uint8, device=device)

@@ -45,9 +45,12 @@ struct Input {
     uint32_t rt_stride;     // words between consecutive entries of that column
 };
 
+#define MFA_NO_WINDOW 0x8000000000000000ull          // addr - MFA_NO_WINDOW >= 16 for every real address
+__device__ __forceinline__ void input_drop_window(Input& in) { in.blk = MFA_NO_WINDOW; in.pblk = MFA_NO_WINDOW; }
+
 __device__ __forceinline__ void input_reset(Input& in, uint64_t base, uint32_t len) {
     in.base = base; in.len = len;
-    in.blk = ~(uint64_t)0; in.pblk = ~(uint64_t)0;
+    input_drop_window(in);
     in.run_lo = in.run_hi = 0; in.run_ch = 0x100u;
     in.per_lo = in.per_hi = 0; in.per_q = 0; in.dual_p = 0;
     in.prev_lo = in.prev_hi = 0; in.prev_q = 0;
@@ -145,26 +148,64 @@ __device__ __forceinline__ uint4 load16(const uint8_t* bytes, uint64_t blk) {
     return *reinterpret_cast<const uint4*>(bytes + blk);
 }
 
-// the byte at scan index i; i advances by one per call
+// ---- the byte window -----------------------------------------------------------------------------------
+// Every lane keeps 16 bytes of its string in registers (w0..w3, the bytes at [blk, blk + 16) of the batch, any alignment) and
+// 16 more that it expects to need next (p0..p3 at pblk).  The windows are turned over by the whole wave at once, every 16th
+// iteration of the main loop (window_turn): a lane that walks step by step then finds its next 16 bytes already there, asked
+// for 16 iterations earlier, and no iteration in between issues a load.  (With windows that every lane renewed when it ran off
+// its own, some lane did so in every iteration, and every iteration waited for the load issued in the one before: half of the
+// time of a plain walk.)  A lane that starts a string or lands after a jump loads its window on the spot, and with it the one
+// it will want at the next turn.
+
+// address of the 16-byte window whose FIRST byte in scan order is scan index j; kept inside [0, total16)
 template <bool REV>
-__device__ __forceinline__ uint32_t stream_byte(Input& in, uint32_t i) {
-    const uint64_t addr = scan_addr<REV>(in, i);
-    const uint64_t blk = addr & ~(uint64_t)15;
-    if (blk != in.blk) {
-        if (blk == in.pblk) { in.w0 = in.p0; in.w1 = in.p1; in.w2 = in.p2; in.w3 = in.p3; }
-        else { uint4 d = load16(in.bytes, blk); in.w0 = d.x; in.w1 = d.y; in.w2 = d.z; in.w3 = d.w; }
-        in.blk = blk;
-        // issue the load of the block that follows in scan order; it is consumed 16 steps from now
-        const uint64_t nb = REV ? blk - 16u : blk + 16u;
-        const bool ok = REV ? (blk >= 16u && blk > (in.base & ~(uint64_t)15)) : (nb < in.total16 && nb < in.base + in.len);
-        in.pblk = ~(uint64_t)0;
-        if (ok) { uint4 d = load16(in.bytes, nb); in.p0 = d.x; in.p1 = d.y; in.p2 = d.z; in.p3 = d.w; in.pblk = nb; }
+__device__ __forceinline__ uint64_t window_addr(const Input& in, uint32_t j) {
+    if (REV) { const uint64_t e = in.base + in.len; return e >= (uint64_t)j + 16u ? e - j - 16u : 0; }
+    const uint64_t a = in.base + j;
+    return a + 16u <= in.total16 ? a : in.total16 - 16u;
+}
+
+__device__ __forceinline__ uint4 load16u(const uint8_t* bytes, uint64_t a) {
+    uint4 d;
+    __builtin_memcpy(&d, bytes + a, 16);
+    return d;
+}
+
+// every 16th iteration, all lanes: take the window asked for at the last turn, ask for the one after it.
+// reading = the lane is inside a string (active, i < len)
+template <bool REV>
+__device__ __forceinline__ void window_turn(Input& in, uint32_t i, bool reading) {
+    if (reading && scan_addr<REV>(in, i) - in.pblk < 16u) { in.w0 = in.p0; in.w1 = in.p1; in.w2 = in.p2; in.w3 = in.p3; in.blk = in.pblk; }
+    in.pblk = MFA_NO_WINDOW;
+    if (reading && i + 16u < in.len) {
+        const uint64_t b = window_addr<REV>(in, i + 16u);
+        const uint4 d = load16u(in.bytes, b);
+        in.p0 = d.x; in.p1 = d.y; in.p2 = d.z; in.p3 = d.w; in.pblk = b;
     }
-    const uint32_t o = (uint32_t)addr & 15u;
-    const uint32_t lo = (o & 4u) ? in.w1 : in.w0;
-    const uint32_t hi = (o & 4u) ? in.w3 : in.w2;
-    const uint32_t w = (o & 8u) ? hi : lo;
-    return (w >> ((o & 3u) * 8u)) & 0xffu;
+}
+
+// the byte at scan index i (i < len); to_turn = iterations until the next window_turn, this one included (1..16)
+template <bool REV>
+__device__ __forceinline__ uint32_t stream_byte(Input& in, uint32_t i, uint32_t to_turn) {
+    const uint64_t addr = scan_addr<REV>(in, i);
+    uint64_t o = addr - in.blk;
+    if (o >= 16u) {                                      // a string begins, or a jump has landed here
+        const uint64_t a = window_addr<REV>(in, i);
+        const uint4 d = load16u(in.bytes, a);
+        in.pblk = MFA_NO_WINDOW;
+        if (i + to_turn < in.len) {                      // where the lane will be at the next turn if it walks on step by step
+            const uint64_t b = window_addr<REV>(in, i + to_turn);
+            const uint4 e = load16u(in.bytes, b);
+            in.p0 = e.x; in.p1 = e.y; in.p2 = e.z; in.p3 = e.w; in.pblk = b;
+        }
+        in.w0 = d.x; in.w1 = d.y; in.w2 = d.z; in.w3 = d.w; in.blk = a;
+        o = addr - a;
+    }
+    const uint32_t ob = (uint32_t)o;
+    const uint32_t lo = (ob & 4u) ? in.w1 : in.w0;
+    const uint32_t hi = (ob & 4u) ? in.w3 : in.w2;
+    const uint32_t w = (ob & 8u) ? hi : lo;
+    return (w >> ((ob & 3u) * 8u)) & 0xffu;
 }
 
 // bit k set iff byte k of the 16-byte block differs from c
@@ -176,44 +217,6 @@ __device__ __forceinline__ uint32_t mismatch_mask16(uint4 d, uint32_t c) {
         return (x | (x >> 7) | (x >> 14) | (x >> 21)) & 0xfu;
     };
     return nz4(d.x ^ cc) | (nz4(d.y ^ cc) << 4) | (nz4(d.z ^ cc) << 8) | (nz4(d.w ^ cc) << 12);
-}
-
-// 16 bytes starting at byte s (0..16) of the 32 bytes a0..a3 (little endian)
-__device__ __forceinline__ void window16(uint64_t a0, uint64_t a1, uint64_t a2, uint64_t a3, uint32_t s, uint64_t& lo, uint64_t& hi) {
-    if (s >= 8u) { a0 = a1; a1 = a2; a2 = a3; s -= 8u; }
-    if (s >= 8u) { a0 = a1; a1 = a2; s -= 8u; }              // s == 16
-    if (s) { lo = (a0 >> (8u * s)) | (a1 << (64u - 8u * s)); hi = (a1 >> (8u * s)) | (a2 << (64u - 8u * s)); }
-    else { lo = a0; hi = a1; }
-}
-
-// Register-only: smallest q in 1..8 such that the next nb bytes in scan order, starting at scan index i, are
-// q-periodic with at least two periods visible; 0 if none.  nb = 16 when the block that follows in scan order
-// has been prefetched (the window then spans both register blocks), else the bytes left in the current block.
-template <bool REV>
-__device__ __forceinline__ uint32_t block_period(const Input& in, uint32_t i, uint32_t& nb) {
-    const uint32_t o = (uint32_t)scan_addr<REV>(in, i) & 15u;
-    const uint64_t w_lo = ((uint64_t)in.w1 << 32) | in.w0, w_hi = ((uint64_t)in.w3 << 32) | in.w2;
-    const uint64_t p_lo = ((uint64_t)in.p1 << 32) | in.p0, p_hi = ((uint64_t)in.p3 << 32) | in.p2;
-    const bool ahead = in.pblk == (REV ? in.blk - 16u : in.blk + 16u);
-    uint64_t lo, hi;
-    if (REV) {                                           // the bytes that count end at offset o of the current block
-        if (ahead) { window16(p_lo, p_hi, w_lo, w_hi, o + 1u, lo, hi); nb = 16u; }
-        else { lo = w_lo; hi = w_hi; nb = o + 1u; }        // low nb bytes of the block
-    } else {                                             // ... they start at offset o
-        window16(w_lo, w_hi, ahead ? p_lo : 0, ahead ? p_hi : 0, o, lo, hi);
-        nb = ahead ? 16u : 16u - o;
-    }
-    for (uint32_t q = 1; q <= 8u && 2u * q <= nb; q++) {   // bytes 0..nb-1 of (hi:lo) are the ones that count
-        uint64_t slo, shi;                               // (hi:lo) >> 8q
-        if (q == 8u) { slo = hi; shi = 0; }
-        else { slo = (lo >> (8u * q)) | (hi << (64u - 8u * q)); shi = hi >> (8u * q); }
-        uint64_t dlo = lo ^ slo, dhi = hi ^ shi;
-        const uint32_t m = nb - q;                       // low m bytes of the difference must vanish
-        if (m < 8u) { dlo &= ~(uint64_t)0 >> (64u - 8u * m); dhi = 0; }
-        else if (m < 16u) { dhi &= (m == 8u) ? 0 : (~(uint64_t)0 >> (64u - 8u * (m - 8u))); }
-        if ((dlo | dhi) == 0) return q;
-    }
-    return 0u;
 }
 
 // smallest offset q in [p, e) with bytes[q] != c, or e
@@ -353,102 +356,8 @@ __device__ __forceinline__ uint32_t run_blocks_fwd(const uint8_t* p, uint32_t nb
     return ~0u;
 }
 
-__device__ __forceinline__ uint32_t coop_period_end_fwd(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0,
-                                                        uint32_t q, uint32_t lane) {
-    if (i0 + q >= len) return len;
-    const uint8_t* p = bytes + base;
-    const uint32_t last = len - q;                       // compare j with j+q for i0 <= j < last
-    const uint32_t nblk = (last - i0) >> 4;              // whole 16-byte blocks
-    constexpr int D = MFA_SCAN_DEPTH;                    // 16-byte blocks per lane in flight: D KiB per wave and trip
-    const uint32_t cc = (uint32_t)p[i0] * 0x01010101u;   // q == 1: every byte must equal the first one
-    if (q == 1u) {                                       // byte j differs from the run's byte: the run ends at j
-        const uint32_t r = run_blocks_fwd<MFA_SCAN_DEPTH>(p + i0, nblk, cc, lane);
-        if (r != ~0u) return i0 + r;
-        const uint32_t j = i0 + 16u * nblk + lane;       // fewer than 17 positions left
-        const unsigned long long b1 = __ballot(lane < 17u && j < len && p[j] != (uint8_t)cc);
-        return b1 ? i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b1) : len;
-    }
-    for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
-        uint4 x[D], y[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            const uint32_t t = t0 + 64u * k + lane;
-            x[k] = y[k] = make_uint4(0, 0, 0, 0);
-            if (t < nblk) {
-                __builtin_memcpy(&x[k], p + i0 + 16u * t, 16);
-                __builtin_memcpy(&y[k], p + i0 + 16u * t + q, 16);
-            }
-        }
-        bool any_diff = false;
-#pragma unroll
-        for (int k = 0; k < D; k++) any_diff = any_diff || ((x[k].x ^ y[k].x) | (x[k].y ^ y[k].y) | (x[k].z ^ y[k].z) | (x[k].w ^ y[k].w)) != 0u;
-        if (__any(any_diff)) {
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const uint32_t m = nz16(make_uint4(x[k].x ^ y[k].x, x[k].y ^ y[k].y, x[k].z ^ y[k].z, x[k].w ^ y[k].w));
-                const unsigned long long b = __ballot(m != 0u);
-                if (b) {
-                    const int L = __builtin_ctzll(b);
-                    // byte j differs from byte j+q, the region ends at j+q
-                    return i0 + 16u * (t0 + 64u * k + (uint32_t)L) + (uint32_t)__builtin_ctz(__shfl(m, L)) + q;
-                }
-            }
-        }
-    }
-    const uint32_t j = i0 + 16u * nblk + lane;           // fewer than 16 positions left
-    const bool bad = lane < 16u && j < last && p[j] != p[j + q];
-    const unsigned long long b = __ballot(bad);
-    if (b) return i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b) + q;
-    return len;
-}
-
-// The same for reversed automata: scan index j lives at address base + len - 1 - j, the scan runs towards
-// lower addresses, and "scan[j] == scan[j+q]" reads "byte[a] == byte[a - q]".
-__device__ __forceinline__ uint32_t coop_period_end_rev(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0,
-                                                        uint32_t q, uint32_t lane) {
-    if (i0 + q >= len) return len;
-    const uint8_t* top = bytes + base + (len - 1u - i0);  // address of scan index i0
-    const uint32_t last = len - q;                        // compare j with j+q for i0 <= j < last
-    const uint32_t nblk = (last - i0) >> 4;
-    constexpr int D = MFA_SCAN_DEPTH;
-    for (uint32_t t0 = 0; t0 < nblk; t0 += 64u * D) {
-        uint4 x[D], y[D];
-#pragma unroll
-        for (int k = 0; k < D; k++) {
-            const uint32_t t = t0 + 64u * k + lane;
-            x[k] = y[k] = make_uint4(0, 0, 0, 0);
-            if (t < nblk) {                                // block t = scan indices i0+16t .. i0+16t+15 = addresses top-16t-15 .. top-16t
-                __builtin_memcpy(&x[k], top - 16u * t - 15u, 16);
-                __builtin_memcpy(&y[k], top - 16u * t - 15u - q, 16);
-            }
-        }
-        bool any_diff = false;
-#pragma unroll
-        for (int k = 0; k < D; k++) any_diff = any_diff || ((x[k].x ^ y[k].x) | (x[k].y ^ y[k].y) | (x[k].z ^ y[k].z) | (x[k].w ^ y[k].w)) != 0u;
-        if (__any(any_diff)) {
-#pragma unroll
-            for (int k = 0; k < D; k++) {
-                const uint32_t m = nz16(make_uint4(x[k].x ^ y[k].x, x[k].y ^ y[k].y, x[k].z ^ y[k].z, x[k].w ^ y[k].w));
-                const unsigned long long b = __ballot(m != 0u);
-                if (b) {
-                    const int L = __builtin_ctzll(b);
-                    const uint32_t mm = __shfl(m, L);      // the highest address is the first scan index: highest set bit
-                    const uint32_t off = 15u - (31u - (uint32_t)__builtin_clz(mm));
-                    return i0 + 16u * (t0 + 64u * k + (uint32_t)L) + off + q;
-                }
-            }
-        }
-    }
-    const uint32_t j = i0 + 16u * nblk + lane;
-    const uint8_t* pj = bytes + base + (len - 1u - j);
-    const bool bad = lane < 16u && j < last && *pj != *(pj - q);
-    const unsigned long long b = __ballot(bad);
-    if (b) return i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b) + q;
-    return len;
-}
-
-// Exclusive end (scan index) of the run of equal bytes that starts at scan index i0: the q = 1 case of the scans above with a
-// shallow pipeline (MFA_RUN_DEPTH blocks per lane in flight).  The walk kernels call it for cell reads of one-byte-repeated
+// Exclusive end (scan index) of the run of equal bytes that starts at scan index i0: all lanes look at
+// consecutive 16-byte blocks, a shallow pipeline (MFA_RUN_DEPTH blocks per lane in flight).  The walk kernels call it for cell reads of one-byte-repeated
 // values whose run the region table does not hold -- runs shorter than MFA_REGION_MIN_LEN, or any run when there is no table.
 #ifndef MFA_RUN_DEPTH
 #define MFA_RUN_DEPTH 2
@@ -496,12 +405,6 @@ __device__ __forceinline__ uint32_t coop_run_end(const uint8_t* bytes, uint64_t 
     const uint32_t j = i0 + 16u * nblk + lane;           // fewer than 17 positions left
     const unsigned long long b1 = __ballot(lane < 17u && j < len && *(bytes + base + (len - 1u - j)) != (uint8_t)cc);
     return b1 ? i0 + 16u * nblk + (uint32_t)__builtin_ctzll(b1) : len;
-}
-
-template <bool REV>
-__device__ __forceinline__ uint32_t coop_period_end(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t q,
-                                                    uint32_t lane) {
-    return REV ? coop_period_end_rev(bytes, base, len, i0, q, lane) : coop_period_end_fwd(bytes, base, len, i0, q, lane);
 }
 
 // are the byte ranges [pa, pa+l) and [pb, pb+l) of the batch equal?  All 64 lanes, wave-uniform arguments.

@@ -545,7 +545,7 @@ struct Gen {
     std::string run() {
         const uint32_t N = g.h.n_nodes;
         std::vector<std::string> words = slot_words();
-        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_LOOK_EVERY " << knob("MFA_GEN_LOOK_EVERY", 2) << "u\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 8) << "\n#define MFA_RUN_DEPTH " << knob("MFA_GEN_RUN_DEPTH", 2) << "\n#define MFA_INLINE_SCAN " << knob("MFA_GEN_INLINE_SCAN", 0) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
+        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 8) << "\n#define MFA_RUN_DEPTH " << knob("MFA_GEN_RUN_DEPTH", 2) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
         o << "\n#define REV " << (rev ? "true" : "false") << "\n#define N_WORDS " << words.size() << "\n#define N_KEYS " << (N - 1) << "\n\n";
         const bool huge = jit_slot_registers(g) > 272;
         const uint32_t lanes = huge ? huge_lanes((uint32_t)words.size()) : 64u;
@@ -665,7 +665,7 @@ struct Gen {
              "  bool patient = false;    // a dual period right after the first plain one has failed on this string: wait for two equal movements\n"
              "  unsigned long long st_f_unst = 0, st_f_dual = 0, st_f_room = 0;\n";
         o << "  __shared__ uint64_t rt_cache[MFA_RT_CACHED * (HUGE ? LANES + 1u : 64u)];      // first entries of every lane's region table\n"
-             "  bool first_round = true;\n  uint32_t warm = 0;\n"
+             "  bool first_round = true;\n  uint32_t warm = 0, turn = 0;\n"
              "  unsigned long long occ0 = 0ull, occ1 = 0ull;      // huge automata: slots that may be occupied in some lane (emit_step_chunked)\n"
              "  unsigned long long pocc0 = 0ull, pocc1 = 0ull;    // ... in some lane at some step since the running probes began (each_word)\n"
              "#if HUGE\n  for (uint32_t k = 0; k < N_WORDS; k++) { nxt_mem[2u * k * PSTRIDE] = MFA_EMPTY; nxt_mem[(2u * k + 1u) * PSTRIDE] = 0u; }      // the next set starts empty\n#endif\n";
@@ -694,7 +694,9 @@ struct Gen {
         o << "    const uint32_t tr_i = i, tr_phase = phase, tr_pp = pp, tr_nper = nper; const bool tr_active = active;   // MFA_STATS builds: trace of the first strings\n";
         o << "    const bool final_pass = (i == len);\n    uint32_t ch = 0x100u;\n"
              "    const unsigned long long tmB = stats ? clock64() : 0;\n"
-             "    if (active && !final_pass) ch = stream_byte<REV>(in, i);\n"
+             "    if (turn == 0u) window_turn<REV>(in, i, active && !final_pass);      // the byte windows of all lanes are renewed together\n"
+             "    if (active && !final_pass) ch = stream_byte<REV>(in, i, 16u - turn);\n"
+             "    turn = (turn + 1u) & 15u;\n"
              "    if (stats) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); tm_byte += clock64() - tmB; }\n"
              "    const unsigned long long tmC = stats ? clock64() : 0;\n";
         // decide whether this lane starts a probe: it must sit in a long run of equal bytes
@@ -703,14 +705,6 @@ struct Gen {
              "    const bool ep_busy = __any(phase != 0u);      // probes run in epochs: all lanes that probe do it in the same iterations\n"
              "    if (!ep_busy) { pocc0 = occ0; pocc1 = occ1; } else { pocc0 |= occ0; pocc1 |= occ1; }\n"
              "    if (accel && active && !final_pass && phase == 0u && i >= probe_at && !ep_busy) {\n"
-             "#if MFA_INLINE_SCAN\n"
-             "      if (in.rt == nullptr) {                       // no table: look at the next 16 bytes (round-1 scheme, A/B runs only)\n"
-             "        uint32_t nb;\n"
-             "        q = block_period<REV>(in, i, nb);\n"
-             "        probe_at = i + (nb < MFA_LOOK_EVERY ? nb : MFA_LOOK_EVERY);      // next look if nothing comes of this one\n"
-             "        if (nb < 8u) q = 0u;\n"
-             "      } else\n"
-             "#endif\n"
              "      if (in.per_q != 0u && in.per_lo <= i && i < in.per_hi) q = in.per_q;      // still inside the region found last\n"
              "      else if (in.rt != nullptr) {                  // regions come from the pre-pass table (regions.hip): nothing to measure\n"
              "        uint32_t rl, rh, rq, rn;\n"
@@ -722,18 +716,6 @@ struct Gen {
              "    }\n"
              "    if (stats) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); tm_look += clock64() - tmC; }\n"
              "    const unsigned long long tm0 = stats ? clock64() : 0;\n"
-             "#if MFA_INLINE_SCAN\n"
-             "    bool need_scan = q != 0u && !(in.per_q == q && in.per_lo <= i && i < in.per_hi);\n"
-             "    for (unsigned long long sb = __ballot(need_scan); sb; sb &= sb - 1ull) {          // one string at a time, all lanes scanning\n"
-             "      const int L = __builtin_ctzll(sb);\n"
-             "      const uint64_t sbase = ((uint64_t)__shfl((uint32_t)(in.base >> 32), L) << 32) | __shfl((uint32_t)in.base, L);\n"
-             "      const uint32_t r = coop_period_end<REV>(bytes, sbase, __shfl(len, L), __shfl(i, L), __shfl(q, L), lane);\n"
-             "      if (lane == (uint32_t)L) {\n"
-             "        if (in.per_q != 0u) { in.prev_lo = in.per_lo; in.prev_hi = in.per_hi; in.prev_q = in.per_q; }\n"
-             "        in.per_hi = r; in.per_lo = i; in.per_q = q; st_scan++;\n"
-             "      }\n"
-             "    }\n"
-             "#endif\n"
              "    if (stats) tm_scan += clock64() - tm0;\n"
              "    if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }\n"
              "    if (q != 0u && q * mult > 16u) mult = 1u;\n"
@@ -776,7 +758,7 @@ struct Gen {
         each_word(words, wl, "          ", "const int32_t d = Dual(DW_).d; SD_WR(K_, d); fits = fits && d == (int32_t)(int16_t)d;");
         o << "        }\n      }\n";
         each_word(words, wl, "      ", "const Dual t = DW_; CW_ = t.v + skip * (uint32_t)t.d;");
-        o << "      if (skip) { i += skip * pp; in.blk = ~(uint64_t)0; in.pblk = ~(uint64_t)0; probe_at = i + 1u + pp; }\n";
+        o << "      if (skip) { i += skip * pp; input_drop_window(in); probe_at = i + 1u + pp; }\n";
         o << "      else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);\n";
         o << "      if (phase == 1u) pk++;\n      if (stats) tm_dual += clock64() - tm1;\n";
         o << "    } else {\n";

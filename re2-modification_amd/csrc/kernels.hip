@@ -60,7 +60,8 @@ struct DevImg {
 // word index of (buf, node, w) for this lane:  (((buf * N + node) * W + w) * 64 + lane
 template <int K>
 struct SlotLayout {
-    static constexpr int W = 3 + 3 * K;      // P, Q, R, then per cell start, len, flags
+    static constexpr int W = 4 + 3 * K;      // P, Q, R (low word), then per cell start, len, flags, then R's high word
+    static constexpr int RHI = 3 + 3 * K;    // R = 5 bits per level of the unset-cell recursion, K + 1 levels: 50 bits for nine cells
 };
 
 template <int K, bool LDS_SLOTS>
@@ -87,6 +88,7 @@ struct Walker {
     Slots<K, LDS_SLOTS> S;
     Input    in;
     uint32_t curbuf;         // wave-uniform
+    uint32_t turn = 0;       // wave-uniform: iterations since the byte windows were last turned over (device_common.h)
     // per-lane
     bool     active;         // has a string in flight
     bool     accept;
@@ -105,12 +107,13 @@ struct Walker {
     }
 
     // insert (P,Q,R,m) into the next-set slot of `node` if it beats what is there
-    __device__ __forceinline__ void insert(bool pred, uint32_t node, uint32_t P, uint32_t Q, uint32_t R, const Mem<K>& m) {
+    __device__ __forceinline__ void insert(bool pred, uint32_t node, uint32_t P, uint32_t Q, uint64_t R, const Mem<K>& m) {
         uint32_t nb = curbuf ^ 1u;
-        uint32_t eP = *S.at(nb, node, 0), eQ = *S.at(nb, node, 1), eR = *S.at(nb, node, 2);
+        uint32_t eP = *S.at(nb, node, 0), eQ = *S.at(nb, node, 1);
+        const uint64_t eR = ((uint64_t)*S.at(nb, node, SlotLayout<K>::RHI) << 32) | *S.at(nb, node, 2);
         bool win = pred && (P < eP || (P == eP && (Q < eQ || (Q == eQ && R < eR))));
         if (win) {
-            *S.at(nb, node, 0) = P; *S.at(nb, node, 1) = Q; *S.at(nb, node, 2) = R;
+            *S.at(nb, node, 0) = P; *S.at(nb, node, 1) = Q; *S.at(nb, node, 2) = (uint32_t)R; *S.at(nb, node, SlotLayout<K>::RHI) = (uint32_t)(R >> 32);
 #pragma unroll
             for (int c = 0; c < K; c++) {
                 *S.at(nb, node, 3 + 3 * c) = m.start[c];
@@ -161,7 +164,7 @@ struct Walker {
     // MFA::evaluateState (mfa.cpp:136-200) for the lanes in `live`, all of which sit on `node`
     // with state (pos, m).  LEVEL = recursion depth through "unset cell" edges (mfa.cpp:148-160).
     template <int LEVEL>
-    __device__ __forceinline__ void eval_node(uint32_t node, bool live, uint32_t pos, Mem<K>& m, uint32_t Q, uint32_t Rprefix) {
+    __device__ __forceinline__ void eval_node(uint32_t node, bool live, uint32_t pos, Mem<K>& m, uint32_t Q, uint64_t Rprefix) {
         live = suffix_ok(live, m);
         if (!__any(live)) return;
         const bool here    = live && !final_pass && pos == i;     // may consume (mfa.cpp:161)
@@ -171,7 +174,7 @@ struct Walker {
         for (uint32_t e = e0; e < e1; e++) {
             const uint2 ed = g.edges[e];                           // uniform -> scalar load
             const uint32_t label = ed.x & 0xffu, eflags = (ed.x >> 8) & 0xffu, target = ed.x >> 16, actions = ed.y;
-            const uint32_t R = Rprefix | ((e - e0 + 1u) << (5 * (K - LEVEL)));
+            const uint64_t R = Rprefix | ((uint64_t)(e - e0 + 1u) << (5 * (K - LEVEL)));
             if (eflags & MFA_EDGE_EPS) {                           // mfa.cpp:143-147 -> finish keeps it iff pos == len
                 if (live && pos == in.len) accept = true;
                 continue;
@@ -225,7 +228,7 @@ struct Walker {
         if (__any(reinsert)) {
             // the state itself goes back into the set; at LEVEL 0 it is the old object (older than
             // anything created this step: Q = R = 0), deeper it is the state the unset-cell edge made
-            insert(reinsert, node, (pos << 4) | first_name(m), LEVEL == 0 ? 0u : Q, LEVEL == 0 ? 0u : Rprefix, m);
+            insert(reinsert, node, (pos << 4) | first_name(m), LEVEL == 0 ? 0u : Q, LEVEL == 0 ? (uint64_t)0 : Rprefix, m);
         }
     }
 
@@ -249,7 +252,9 @@ struct Walker {
     __device__ __forceinline__ bool step() {
         final_pass = (i == in.len);
         ch = 0x100u;
-        if (active && !final_pass) ch = stream_byte<REV>(in, i);
+        if (turn == 0u) window_turn<REV>(in, i, active && !final_pass);
+        if (active && !final_pass) ch = stream_byte<REV>(in, i, 16u - turn);
+        turn = (turn + 1u) & 15u;
         any_next = false;
         for (uint32_t n = 0; n < g.n_nodes; n++) {
             uint32_t P = active ? *S.at(curbuf, n, 0) : kEmpty;

@@ -432,6 +432,37 @@ def test_more_than_four_cells(regex, tmp_path, monkeypatch):
     assert want.sum() > 0
 
 
+# nondeterministic automata with seven cells: several ways to the same node and position with different cell contents, and reads
+# of cells that were never set (mfa.cpp:148-160 recurses once per such cell: the table-driven kernel's tie-break key has one
+# 5-bit digit per level and does not fit 32 bits from six cells on)
+MANY_CELLS_TIES = ["({a}:1|b)({a}:2|b)({a}:3|b)({a}:4|b)({a}:5|b)({a}:6|b)({a}:7|b)(&1|&2)(&3|&4)(&5|&6)&7",
+                   "{a*}:1{a*}:2{a*}:3{a*}:4{a*}:5{a*}:6{a*}:7b&7&6&5&4&3&2&1"]
+
+
+@pytest.mark.parametrize("regex", MANY_CELLS_TIES, ids=["unset7", "split7"])
+def test_many_cells_tie_breaks(regex, tmp_path, monkeypatch):
+    import random
+    blob = _front_end_blob(regex, tmp_path)
+    assert image.blob_info(blob)["n_cells"] == 7
+    rng = random.Random(7 + len(regex))
+    strings = [b"", b"bbbbbbb", b"bbbbbba" + b"a", b"aaaaaaa" + b"aaaa", b"abababa" + b"aaaa", b"ab", b"aab" + b"aa", b"aaab" + b"aaa"]
+    for _ in range(500):
+        if regex.startswith("("):
+            head = "".join(rng.choice("ab") for _ in range(7))
+            tail = "".join(rng.choice(["a", ""]) for _ in range(4))
+            strings.append((head + tail).encode())
+        else:
+            n = rng.randint(0, 9)
+            strings.append(("a" * n + "b" + "a" * (n if rng.random() < 0.7 else rng.randint(0, 9))).encode())
+    want = oracle_lib.OracleImage(blob).match(strings)
+    for mode in ("generic", "specialised"):
+        monkeypatch.setenv("MFA_JIT", "0" if mode == "generic" else "1")
+        got = gpu_match(capi.Image(blob), strings)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "%s: %d mismatches, first %r want %d" % (mode, bad.size, strings[bad[0]], want[bad[0]])
+    assert 0 < want.sum() < len(strings)
+
+
 def test_large_tabulated_automaton(tmp_path):
     """a memory-less automaton whose subset construction has hundreds of state sets (the table does not fit LDS): Thompson image
     of (a|b)*a(a|b)^8, forward walk, against the CPU restatement"""
