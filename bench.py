@@ -378,7 +378,7 @@ def main():
     ap.add_argument("--region-streams", type=int, default=1, help="HIP streams the region launches alternate between (the tail of one launch overlaps the start of the next)")
     ap.add_argument("--region-priority", type=int, default=0, help="stream priority of the region streams (-1 = high)")
     ap.add_argument("--region-launches", default="3",
-                    help="region pre-pass launches per step: 'per-example' (10), 'one', or a number g: the examples, laid out in the batch "
+                    help="region pre-pass launches per step: 'per-example' (10), 'one', explicit group sizes 'a,b,c', or a number g: the examples, laid out in the batch "
                          "costliest walk first, are scanned in g launches of consecutive examples; the walks of a group start when "
                          "their group is scanned and run beside the next group's scan")
     ap.add_argument("--walk-waves", type=int, default=0, help="development: cap the walk kernels at this many waves per CU (MFA_WALK_WAVES_PER_CU)")
@@ -461,16 +461,24 @@ def main():
         a = shards[ex]["first"]
         return a, a + shards[ex]["n"]
 
-    n_groups = {"per-example": len(layout), "one": 1}.get(args.region_launches) or max(1, min(len(layout), int(args.region_launches)))
-    # groups of consecutive examples with about equal bytes
-    groups, acc, cur = [], 0, []
-    for ex in layout:
-        cur.append(ex)
-        acc += shards[ex]["nbytes"]
-        if acc >= total_bytes * (len(groups) + 1) / n_groups - 1 and len(groups) < n_groups - 1:
-            groups.append(cur); cur = []
-    if cur:
-        groups.append(cur)
+    if "," in args.region_launches:
+        # explicit group sizes (examples per launch, in layout order)
+        sizes_g = [int(t) for t in args.region_launches.split(",")]
+        assert sum(sizes_g) == len(layout) and min(sizes_g) > 0, "--region-launches a,b,c: group sizes must add up to the number of examples"
+        groups, at = [], 0
+        for g_n in sizes_g:
+            groups.append(layout[at:at + g_n]); at += g_n
+    else:
+        n_groups = {"per-example": len(layout), "one": 1}.get(args.region_launches) or max(1, min(len(layout), int(args.region_launches)))
+        # groups of consecutive examples with about equal bytes
+        groups, acc, cur = [], 0, []
+        for ex in layout:
+            cur.append(ex)
+            acc += shards[ex]["nbytes"]
+            if acc >= total_bytes * (len(groups) + 1) / n_groups - 1 and len(groups) < n_groups - 1:
+                groups.append(cur); cur = []
+        if cur:
+            groups.append(cur)
     ev_g0 = [torch.cuda.Event(enable_timing=True) for _ in groups]
     ev_g1 = [torch.cuda.Event(enable_timing=True) for _ in groups]
 
