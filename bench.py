@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "re2-modification_amd"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PARITY_N = 48                  # strings per example whose GPU answers are re-checked on the CPU after the timed region
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02b_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02c_traffic.json")
 
 
 def spawn_ranks(args):
@@ -366,8 +366,8 @@ def secondary_config5(device, capi, corpus, n_strings=125000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--strings-per-example", type=int, default=125000,
                     help="strings of each example per GPU (125000 x 10 examples x 8 GPUs = the 10M-string batch)")
     ap.add_argument("--min-len", type=int, default=1024)

@@ -55,7 +55,7 @@ traffic = {
 with open(os.path.join(dst, tag + "_traffic.json"), "w") as f:
     json.dump(traffic, f, indent=1)
     f.write("\n")
-span = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "span_from_trace.py"), one("stats/**/*kernel_trace.csv"), str(n_region), str(n_walk)],
+span = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "span_from_trace.py"), one("stats/**/*kernel_trace.csv"), str(n_region), str(n_walk), "1", str(bench["warmup"]), str(bench["steps"])],
                       capture_output=True, text=True).stdout
 with open(os.path.join(dst, tag + "_span_check.txt"), "w") as f:
     f.write(span)
