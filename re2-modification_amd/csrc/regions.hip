@@ -183,7 +183,7 @@ __device__ __forceinline__ void scan_reset(Scan& sc) {
 }
 
 // ---- rows in flight -----------------------------------------------------------------------------------------------
-// A row is two loads per lane: the lane's 16-byte block and the 8 bytes behind it.  Rows are read whole, lanes past the last
+// A row is the lane's 16-byte block and the 8 bytes behind it (one load per lane, one more in the last lane).  Rows are read whole, lanes past the last
 // block re-read it, and the 8 bytes behind the very last block of the batch come from inside it; what such lanes load is never
 // looked at (their blocks are forced).  Addresses are the string's (wave-uniform) base plus a 32-bit offset per lane.
 //
@@ -203,8 +203,16 @@ __device__ __forceinline__ void row_request(const uint8_t* sbase, const Geo& g, 
     off = off < g.lastoff ? off : g.lastoff;
     uint32_t yo = off + 16u;
     yo = yo < g.ylim ? yo : g.ylim;
-    asm volatile("global_load_dwordx4 %0, %2, %4\n\tglobal_load_dwordx2 %1, %3, %4"
-                 : "=&v"(r.x), "=&v"(r.y) : "v"(off), "v"(yo), "s"(sbase) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(r.x) : "v"(off), "s"(sbase) : "memory");
+    // the 8 bytes behind a block are the head of the next lane's block (row_tail); only the last lane has to ask for them
+    if (lane == 63u) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(r.y) : "v"(yo), "s"(sbase) : "memory");
+}
+// y of an arrived row: lane L takes the first two words of lane L + 1's block (DPP wave_shl:1), lane 63 keeps what it loaded.
+// (The lane of the string's last block gets its own head this way -- lanes past the last block re-read it -- but the blocks from
+// endblk on are forced dirty and their y is never looked at.)
+__device__ __forceinline__ uint2 row_tail(const Row& r) {
+    return make_uint2((uint32_t)__builtin_amdgcn_update_dpp((int)r.y[0], (int)r.x[0], 0x130, 0xf, 0xf, false),
+                      (uint32_t)__builtin_amdgcn_update_dpp((int)r.y[1], (int)r.x[1], 0x130, 0xf, 0xf, false));
 }
 // r was requested before the row requested last: once at most that one's two loads are outstanding, r has arrived
 __device__ __forceinline__ void row_wait_older(Row& r) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(r.x), "+v"(r.y) :: "memory"); }
@@ -370,7 +378,7 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
 #define MFA_ROW(k, cur, nxt)                                                                                                  \
         row_request(sbase, g, row + (k) + 1, lane, nxt);                                                                      \
         row_wait_older(cur);                                                                                                  \
-        scan_row(sc, lane, g, row + (k), make_uint4(cur.x[0], cur.x[1], cur.x[2], cur.x[3]), make_uint2(cur.y[0], cur.y[1])); \
+        scan_row(sc, lane, g, row + (k), make_uint4(cur.x[0], cur.x[1], cur.x[2], cur.x[3]), row_tail(cur));                  \
         go = sc.st.ncand < 64u && row + (k) + 1 < g.nrows;
         for (int32_t row = 0; more; row += 2) {
             bool go;
