@@ -742,7 +742,11 @@ struct Gen {
         o << "      uint32_t skip = 0;\n";
         o << "      if (p2) {\n        tb_min(TBacc, TB.a, TB.b);\n        pk++;\n";
         o << "        if (pk == pp) {\n          const int64_t periods = tb_steps(TBacc);\n          bool same = !accept && any_next && periods > 1 && fits;\n";
-        each_word(words, wl, "          ", "const Dual t = DW_; same = same && t.d == SA_RD(K_) && (int32_t)(t.v - SB_RD(K_)) == SA_RD(K_);");
+        // no short-circuit in the comparisons over the words: a chain of `&&` is a chain of branches with one probe-image read (LDS, or
+        // the L2-resident scratch area) waited for in each -- the differences are or-ed together instead and the reads go out together
+        o << "          if (same) {\n            uint32_t differs = 0u;\n";
+        each_word(words, wl, "            ", "const Dual t = DW_; const int32_t sa = SA_RD(K_); differs |= (uint32_t)(t.d ^ sa) | (uint32_t)((int32_t)(t.v - SB_RD(K_)) ^ sa);");
+        o << "            same = differs == 0u;\n          }\n";
         o << "          if (same) skip = (uint32_t)(periods - 1 < (int64_t)0x00ffffff ? periods - 1 : (int64_t)0x00ffffff);\n";
         o << "          phase = 0u;\n";
         o << "          if (skip) { backoff = 8u; fails = 0u; st_hit++; st_skip += (unsigned long long)skip * pp; }\n";
@@ -755,7 +759,7 @@ struct Gen {
              "          if (nper == 1u && !patient && pp > 2u) patient = true; else mult = mult % 8u + 1u;\n"
              "          if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }\n"
              "        } else {\n";
-        each_word(words, wl, "          ", "const int32_t d = Dual(DW_).d; SD_WR(K_, d); fits = fits && d == (int32_t)(int16_t)d;");
+        each_word(words, wl, "          ", "const int32_t d = Dual(DW_).d; SD_WR(K_, d); fits &= (d == (int32_t)(int16_t)d);");
         o << "        }\n      }\n";
         each_word(words, wl, "      ", "const Dual t = DW_; CW_ = t.v + skip * (uint32_t)t.d;");
         o << "      if (skip) { i += skip * pp; input_drop_window(in); probe_at = i + 1u + pp; }\n";
@@ -769,10 +773,11 @@ struct Gen {
         // period's; a lane is ready for the dual period once two consecutive movements agree.  All lanes of an epoch reach
         // their period boundaries in the same iteration and go on together: to the dual period when every one of them is
         // ready or has run out of patience (MFA_PROBE_PERIODS plain periods) or of periodic input.
-        o << "    if (phase == 1u && pk == pp) {\n      bool eqd = nper != 0u, occ = nper == 0u && !patient && pp > 2u;      // short periods: waiting for a second one costs next to nothing\n      fits = true;\n";
-        each_word(words, wl, "      ", "const uint32_t v = CW_, b = SB_RD(K_); const int32_t d = (int32_t)(v - b); eqd = eqd && d == SA_RD(K_); SA_WR(K_, d); "
-                                     "SB_WR(K_, v); fits = fits && d == (int32_t)(int16_t)d; if (ISP_) occ = occ && (v == MFA_EMPTY) == (b == MFA_EMPTY);");
+        o << "    if (phase == 1u && pk == pp) {\n      bool eqd = nper != 0u, occ = nper == 0u && !patient && pp > 2u;      // short periods: waiting for a second one costs next to nothing\n      uint32_t moved = 0u, wide = 0u, vacated = 0u;\n";
+        each_word(words, wl, "      ", "const uint32_t v = CW_, b = SB_RD(K_); const int32_t d = (int32_t)(v - b); moved |= (uint32_t)(d ^ SA_RD(K_)); SA_WR(K_, d); "
+                                     "SB_WR(K_, v); wide |= (uint32_t)(d ^ (int32_t)(int16_t)d); if (ISP_) vacated |= (uint32_t)((v == MFA_EMPTY) != (b == MFA_EMPTY));");
         // first period: the same slots occupied before and after it is taken as "probably settled already"
+        o << "      eqd = eqd && moved == 0u; occ = occ && vacated == 0u; fits = wide == 0u;\n";
         o << "      nper++; pk = 0u; stable = (eqd || occ) && fits;\n    }\n";
         o << "    {\n      const bool at_b = phase == 1u && pk == 0u && nper != 0u;\n"
              "      if (__any(at_b)) {\n"

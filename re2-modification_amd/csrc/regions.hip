@@ -274,37 +274,38 @@ __device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo
     uint32_t lo = 0, hi = 0;
     const uint32_t q = st.cq;
     if (lane < ncand) {
-        const int64_t vlo = (int64_t)g.off0, vhi = (int64_t)g.off0 + (int64_t)g.len - (int64_t)q;   // valid j (relative to a0): vlo <= j < vhi
-        auto ld8 = [&](uint64_t addr) -> uint64_t {
+        // positions are byte offsets from a0 (32 bits: a string is shorter than 16 MB); valid j: vlo <= j < vhi
+        const int32_t vlo = (int32_t)g.off0, vhi = (int32_t)g.off0 + (int32_t)g.len - (int32_t)q;
+        const uint8_t* const sbase = bytes + g.a0;
+        auto ld8 = [&](uint32_t off) -> uint64_t {                  // 8 bytes at a0 + off, 0 beyond the batch
             uint64_t v = 0;
-            if (addr + 8u <= total16) v = *reinterpret_cast<const uint64_t*>(bytes + addr);
+            if (off <= g.ylim) v = *reinterpret_cast<const uint64_t*>(sbase + off);
             return v;
         };
         {   // the last real mismatch in block X, or the first valid position of X
-            const uint64_t addr = g.a0 + 16u * (uint64_t)st.cx;
-            const uint64_t p0 = ld8(addr), p1 = ld8(addr + 8u), p2 = ld8(addr + 16u);
+            const int32_t w0 = 16 * st.cx;
+            const uint64_t p0 = ld8((uint32_t)w0), p1 = ld8((uint32_t)w0 + 8u), p2 = ld8((uint32_t)w0 + 16u);
             uint32_t m = nz8(p0 ^ shr_bytes(p0, p1, q)) | (nz8(p1 ^ shr_bytes(p1, p2, q)) << 8);
-            const int64_t w0 = 16 * (int64_t)st.cx;
             uint32_t valid = 0xffffu;
             if (vlo > w0) valid &= vlo - w0 >= 16 ? 0u : (0xffffu << (uint32_t)(vlo - w0));
             if (vhi < w0 + 16) valid &= vhi <= w0 ? 0u : (0xffffu >> (uint32_t)(w0 + 16 - vhi));
             m &= valid;
-            const int64_t lo_abs = m ? w0 + (31 - __builtin_clz(m)) + 1 : (w0 > vlo ? w0 : vlo);
+            const int32_t lo_abs = m ? w0 + (31 - __builtin_clz(m)) + 1 : (w0 > vlo ? w0 : vlo);
             lo = (uint32_t)(lo_abs - vlo);
         }
         {   // the first real mismatch in blocks Y, Y + 1
-            const uint64_t addr = g.a0 + 16u * (uint64_t)st.cy;
-            const uint64_t p0 = ld8(addr), p1 = ld8(addr + 8u), p2 = ld8(addr + 16u), p3 = ld8(addr + 24u), p4 = ld8(addr + 32u);
+            const int32_t w0 = 16 * st.cy;
+            const uint64_t p0 = ld8((uint32_t)w0), p1 = ld8((uint32_t)w0 + 8u), p2 = ld8((uint32_t)w0 + 16u), p3 = ld8((uint32_t)w0 + 24u),
+                           p4 = ld8((uint32_t)w0 + 32u);
             uint32_t m = nz8(p0 ^ shr_bytes(p0, p1, q)) | (nz8(p1 ^ shr_bytes(p1, p2, q)) << 8) | (nz8(p2 ^ shr_bytes(p2, p3, q)) << 16) |
                          (nz8(p3 ^ shr_bytes(p3, p4, q)) << 24);
-            const int64_t w0 = 16 * (int64_t)st.cy;
             uint32_t valid = 0xffffffffu;
             if (vhi < w0 + 32) valid = vhi <= w0 ? 0u : (0xffffffffu >> (uint32_t)(w0 + 32 - vhi));
             m &= valid;
-            int64_t hi_abs;
-            if (m) hi_abs = w0 + __builtin_ctz(m) + (int64_t)q;
-            else if (vhi < w0 + 32) hi_abs = vlo + (int64_t)g.len;
-            else hi_abs = w0 + 32 + (int64_t)q;
+            int32_t hi_abs;
+            if (m) hi_abs = w0 + __builtin_ctz(m) + (int32_t)q;
+            else if (vhi < w0 + 32) hi_abs = vlo + (int32_t)g.len;
+            else hi_abs = w0 + 32 + (int32_t)q;
             hi = (uint32_t)(hi_abs - vlo);
         }
         keep = hi > lo && hi - lo >= MFA_REGION_MIN_LEN && hi <= g.len;
@@ -403,8 +404,10 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     uint64_t blocks = (n + 3) / 4;
     const uint64_t cap = cus * 8u * 64u;                          // beyond this waves take several strings each
     if (blocks > cap) blocks = cap;
-    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, d_bytes, d_offsets, n, d_table);
-    else hipLaunchKernelGGL((region_scan_kernel<0>), dim3((unsigned)blocks), dim3(256), 0, s, d_bytes, d_offsets, n, d_table);
+    const char* el = getenv("MFA_REGION_LDS");                    // development: unused dynamic LDS per workgroup, to lower the occupancy
+    const unsigned lds = el ? (unsigned)atoi(el) : 0u;
+    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
+    else hipLaunchKernelGGL((region_scan_kernel<0>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
     HIP_TRY(hipGetLastError());
     return MFA_OK;
 }
