@@ -214,8 +214,9 @@ __device__ __forceinline__ uint2 row_tail(const Row& r) {
     return make_uint2((uint32_t)__builtin_amdgcn_update_dpp((int)r.y[0], (int)r.x[0], 0x130, 0xf, 0xf, false),
                       (uint32_t)__builtin_amdgcn_update_dpp((int)r.y[1], (int)r.x[1], 0x130, 0xf, 0xf, false));
 }
-// r was requested before the row requested last: once at most that one's two loads are outstanding, r has arrived
-__device__ __forceinline__ void row_wait_older(Row& r) { asm volatile("s_waitcnt vmcnt(2)" : "+v"(r.x), "+v"(r.y) :: "memory"); }
+// r was requested before the YOUNGER rows requested last: once at most their loads (two each) are outstanding, r has arrived
+template <int YOUNGER>
+__device__ __forceinline__ void row_wait_older(Row& r) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.x), "+v"(r.y) : "n"(2 * YOUNGER) : "memory"); }
 __device__ __forceinline__ void row_wait_all(Row& r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.x), "+v"(r.y) :: "memory"); }
 
 // one row: x = this lane's block, y = the 8 bytes behind it
@@ -346,13 +347,14 @@ __device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo
 }
 
 // ---- kernels ---------------------------------------------------------------------------------------------------
+constexpr int kRegionDepth = 2;      // 3 and 4 are more robust alone at low occupancy (5 waves per SIMD: 4.26 against 4.87 ms) but slower inside a step: more registers, fewer waves beside a walk wave (5.18-5.32 / 5.33-5.44 / 5.63-5.69 ms)
 // MODE 1: streaming phase only (development).
 // One wave per string (the hardware dispatcher hands out strings), the next row's loads issued before the current row is looked
 // at.  A persistent form (as many waves as the chip holds, strings by ticket, the next string's offsets and first row requested
 // before the current string's candidates are resolved) was built and measured: 4.48 ms against 4.30 ms for this one on the
 // headline shard, and worse beside the walk kernels -- with eight waves per SIMD the dispatcher's own refill hides a wave's
 // start-up latencies as well as software pipelining does.
-template <int MODE>
+template <int MODE, int DEPTH>
 __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
                                                              uint64_t* __restrict__ table) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -368,28 +370,33 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
         const uint8_t* const sbase = bytes + g.a0;
         Scan sc;
         scan_reset(sc);
-        // Two register sets, rows alternating between them, the loop unrolled by two: while a row is looked at the next one is in
-        // flight (three sets, two rows ahead: 4.00 against 4.05 ms alone, no better beside the walk kernels).  One exit, at the
-        // bottom.  More candidates than lanes to hold them (text made of hundreds of medium runs): the table would carry the
-        // overflow flag whatever comes, and the walk cannot skip much of such a string anyway -- the rest of it is not read.
-        Row r0, r1;
-        r0.x = r1.x = u32x4{0, 0, 0, 0}; r0.y = r1.y = u32x2{0, 0};
+        // DEPTH register sets in rotation, the loop unrolled by DEPTH (all indices are constants after unrolling): while a row is
+        // looked at, the DEPTH - 1 rows after it are in flight.  One exit, at the bottom.  More candidates than lanes to hold them
+        // (text made of hundreds of medium runs): the table would carry the overflow flag whatever comes, and the walk cannot skip
+        // much of such a string anyway -- the rest of it is not read.
+        Row r[DEPTH];
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) { r[k].x = u32x4{0, 0, 0, 0}; r[k].y = u32x2{0, 0}; }
         bool more = g.nrows > 0;
-        if (more) row_request(sbase, g, 0, lane, r0);
-#define MFA_ROW(k, cur, nxt)                                                                                                  \
-        row_request(sbase, g, row + (k) + 1, lane, nxt);                                                                      \
-        row_wait_older(cur);                                                                                                  \
-        scan_row(sc, lane, g, row + (k), make_uint4(cur.x[0], cur.x[1], cur.x[2], cur.x[3]), row_tail(cur));                  \
-        go = sc.st.ncand < 64u && row + (k) + 1 < g.nrows;
-        for (int32_t row = 0; more; row += 2) {
-            bool go;
-            MFA_ROW(0, r0, r1)
-            if (go) { MFA_ROW(1, r1, r0) }
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < DEPTH - 1; k++) row_request(sbase, g, k, lane, r[k]);
+        }
+        for (int32_t row = 0; more; row += DEPTH) {
+            bool go = true;
+#pragma unroll
+            for (int k = 0; k < DEPTH; k++) {
+                if (go) {
+                    row_request(sbase, g, row + k + DEPTH - 1, lane, r[(k + DEPTH - 1) % DEPTH]);
+                    row_wait_older<DEPTH - 1>(r[k]);
+                    scan_row(sc, lane, g, row + k, make_uint4(r[k].x[0], r[k].x[1], r[k].x[2], r[k].x[3]), row_tail(r[k]));
+                    go = sc.st.ncand < 64u && row + k + 1 < g.nrows;
+                }
+            }
             more = go;
         }
-#undef MFA_ROW
-        row_wait_all(r0);                                               // nothing of this string is in flight any more
-        row_wait_all(r1);
+#pragma unroll
+        for (int k = 0; k < DEPTH; k++) row_wait_all(r[k]);             // nothing of this string is in flight any more
         if (MODE == 1) { if (lane == 0) tab[0] = sc.st.ncand; continue; }
         finish_string(sc, lane, g, bytes, total16, tab);
     }
@@ -406,8 +413,13 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     if (blocks > cap) blocks = cap;
     const char* el = getenv("MFA_REGION_LDS");                    // development: unused dynamic LDS per workgroup, to lower the occupancy
     const unsigned lds = el ? (unsigned)atoi(el) : 0u;
-    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
-    else hipLaunchKernelGGL((region_scan_kernel<0>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
+    const char* ed = getenv("MFA_REGION_DEPTH");                  // development: rows per wave in rotation (2, 3 or 4)
+    const int depth = ed ? atoi(ed) : kRegionDepth;
+    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 3) hipLaunchKernelGGL((region_scan_kernel<0, 3>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
+    else return MFA_ERR_UNSUPPORTED;
     HIP_TRY(hipGetLastError());
     return MFA_OK;
 }
