@@ -120,6 +120,19 @@ def test_region_tables(pad):
     assert check_tables(strings, tabs) > 300
 
 
+@pytest.mark.parametrize("depth", [2, 3, 4])
+def test_region_tables_every_rotation_depth(depth, monkeypatch):
+    """the region kernel's development variants (rows per wave in rotation, MFA_REGION_DEPTH) give the same tables"""
+    rng = np.random.default_rng(777)
+    strings = [b"", b"a" * 64, b"ab" * 600, b"x" + b"a" * 3000 + b"y" + b"abc" * 700] + _fuzz_strings(rng, 200, 9000)
+    monkeypatch.delenv("MFA_REGION_DEPTH", raising=False)
+    want = scan(strings, 3)
+    monkeypatch.setenv("MFA_REGION_DEPTH", str(depth))
+    got = scan(strings, 3)
+    assert np.array_equal(got, want)
+    check_tables(strings, got)
+
+
 def test_region_table_overflow_keeps_true_regions():
     """more long regions than a table holds: flagged, and what is kept is still true"""
     s = b"".join(bytes([97 + (k % 3)]) * 150 for k in range(60))
