@@ -116,13 +116,15 @@ __device__ __forceinline__ void emit(RegionState& st, uint32_t lane, int32_t x, 
 }
 
 // book-keeping of one row for one period: dirty = ballot of dirty blocks, base = block number of lane 0
+// returns whether a candidate was recorded (emit called, whatever emit then did with it)
 template <int Q>
-__device__ __forceinline__ void book(RegionState& st, uint32_t lane, unsigned long long dirty, int32_t base) {
+__device__ __forceinline__ bool book(RegionState& st, uint32_t lane, unsigned long long dirty, int32_t base) {
     int32_t& last = st.last_dirty[Q];
-    if (dirty == ~0ull && last == base - 1) { last = base + 63; return; }      // nothing clean anywhere: the common dirty case
-    if (dirty == 0ull) return;
+    if (dirty == ~0ull && last == base - 1) { last = base + 63; return false; }      // nothing clean anywhere: the common dirty case
+    if (dirty == 0ull) return false;
+    bool emitted = false;
     const int32_t first = (int32_t)__builtin_ctzll(dirty), top = 63 - (int32_t)__builtin_clzll(dirty);
-    if (base + first - last - 1 >= kCleanMin) emit<Q>(st, lane, last, base + first);
+    if (base + first - last - 1 >= kCleanMin) { emit<Q>(st, lane, last, base + first); emitted = true; }
     // clean stretches between dirty blocks of this row
     unsigned long long z = ~dirty;
     unsigned long long zz = z;
@@ -133,17 +135,40 @@ __device__ __forceinline__ void book(RegionState& st, uint32_t lane, unsigned lo
         int32_t prev = first;
         for (unsigned long long m = dirty & (dirty - 1ull); m; m &= m - 1ull) {
             const int32_t nxt = (int32_t)__builtin_ctzll(m);
-            if (nxt - prev - 1 >= kCleanMin) emit<Q>(st, lane, base + prev, base + nxt);
+            if (nxt - prev - 1 >= kCleanMin) { emit<Q>(st, lane, base + prev, base + nxt); emitted = true; }
             prev = nxt;
         }
     }
     last = base + top;
+    return emitted;
+}
+
+// One row for one period.  A run of equal bytes is clean for every period, text of period 2 for 4, 6 and 8 as well: where a proper
+// divisor D of Q saw the same dirty blocks in this row and stood at the same block before it, Q's book-keeping would repeat D's
+// step by step and every candidate it found would be dropped as covered by D's (emit) -- D's results are copied instead.  (Rows
+// at the ends of strings and of regions are the ones that get here; with eight full book-keepings each they were most of the
+// pass's scalar instructions.)
+struct RowBook { unsigned long long dirty[9]; int32_t before[9]; bool emitted[9]; };
+
+template <int Q, int D>
+__device__ __forceinline__ bool row_same_as(RegionState& st, RowBook& rb) {
+    if constexpr (D >= Q || Q % D != 0) return false;
+    else {
+        if (rb.dirty[Q] != rb.dirty[D] || rb.before[Q] != rb.before[D]) return false;
+        st.last_dirty[Q] = st.last_dirty[D];
+        if (rb.emitted[D]) { st.cand_x[Q] = st.cand_x[D]; st.cand_y[Q] = st.cand_y[D]; }
+        rb.emitted[Q] = rb.emitted[D];
+        return true;
+    }
 }
 
 template <int Q>
-__device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, uint32_t mask, uint32_t settled, int32_t base) {
+__device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, uint32_t mask, uint32_t settled, int32_t base, RowBook& rb) {
     if (settled & qbit(Q)) st.last_dirty[Q] = base - 1;        // every block of the rows skipped before this one was dirty
-    book<Q>(st, lane, __ballot((mask & qbit(Q)) != 0u), base);
+    rb.dirty[Q] = __ballot((mask & qbit(Q)) != 0u);
+    rb.before[Q] = st.last_dirty[Q];
+    if (row_same_as<Q, 4>(st, rb) || row_same_as<Q, 3>(st, rb) || row_same_as<Q, 2>(st, rb) || row_same_as<Q, 1>(st, rb)) return;
+    rb.emitted[Q] = book<Q>(st, lane, rb.dirty[Q], base);
 }
 
 // ---- one string ---------------------------------------------------------------------------------------------
@@ -248,16 +273,21 @@ __device__ __forceinline__ void scan_row(Scan& sc, uint32_t lane, const Geo& g, 
     const uint32_t mask = forced ? kAllDirty : block_mask(x.x, x.y, x.z, x.w, y.x, y.y);
     if (__all(mask == sc.settled)) return;
     const uint32_t was = sc.settled != ~0u ? sc.settled : 0u;
-    row_period<1>(st, lane, mask, was, base);
-    row_period<2>(st, lane, mask, was, base);
-    row_period<3>(st, lane, mask, was, base);
-    row_period<4>(st, lane, mask, was, base);
-    row_period<5>(st, lane, mask, was, base);
-    row_period<6>(st, lane, mask, was, base);
-    row_period<7>(st, lane, mask, was, base);
-    row_period<8>(st, lane, mask, was, base);
-    const uint32_t m0 = __builtin_amdgcn_readfirstlane(mask);
-    sc.settled = __all(mask == m0) ? m0 : ~0u;
+    RowBook rb;
+    row_period<1>(st, lane, mask, was, base, rb);
+    row_period<2>(st, lane, mask, was, base, rb);
+    row_period<3>(st, lane, mask, was, base, rb);
+    row_period<4>(st, lane, mask, was, base, rb);
+    row_period<5>(st, lane, mask, was, base, rb);
+    row_period<6>(st, lane, mask, was, base, rb);
+    row_period<7>(st, lane, mask, was, base, rb);
+    row_period<8>(st, lane, mask, was, base, rb);
+    // What the next rows are compared with is the mask of this row's LAST block: rows that are uniformly like it continue its
+    // stretch (a block clean for a period looks 8 bytes beyond itself, so the first bytes of the next row are covered), and a row
+    // that is uniformly dirty for a period follows a block that was.  Waiting for a whole uniform row instead cost one more trip
+    // through this book-keeping after every string start and every region boundary.
+    const int32_t b63 = base + 63;
+    sc.settled = (b63 < g.endblk) ? (uint32_t)__builtin_amdgcn_readlane((int)mask, 63) : ~0u;
     sc.vp = 0u;
     if (sc.settled != ~0u) {
 #pragma unroll
