@@ -343,8 +343,10 @@ __device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo
     }
     // ---- drop regions that a region of a divisor period covers
     for (uint32_t f = 0; f < ncand; f++) {
-        const uint32_t qf = __shfl(q, (int)f), lof = __shfl(lo, (int)f), hif = __shfl(hi, (int)f);
-        const bool kf = __shfl((int)keep, (int)f) != 0;
+        // f is wave-uniform: v_readlane (a scalar result a few cycles later), not a trip through the LDS crossbar
+        const uint32_t qf = (uint32_t)__builtin_amdgcn_readlane((int)q, (int)f), lof = (uint32_t)__builtin_amdgcn_readlane((int)lo, (int)f),
+                       hif = (uint32_t)__builtin_amdgcn_readlane((int)hi, (int)f);
+        const bool kf = __builtin_amdgcn_readlane((int)keep, (int)f) != 0;
         if (!kf) continue;
         const bool divides = ((0x804020108824aaffull >> (((qf - 1u) * 8u + (q - 1u)) & 63u)) & 1ull) != 0ull;     // bit 8 (qf-1) + (q-1): qf divides q
         if (lane < ncand && lane != f && qf < q && divides && lof <= lo + 16u && hif + 16u >= hi) keep = false;
@@ -355,7 +357,7 @@ __device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo
         const uint32_t mine = hi - lo;
         uint32_t longer = 0;
         for (uint32_t f = 0; f < ncand; f++) {
-            const uint32_t lf = __shfl(mine, (int)f);
+            const uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)f);
             if (((kb >> f) & 1ull) && (lf > mine || (lf == mine && f < lane))) longer++;
         }
         keep = keep && longer < MFA_REGION_MAX;
@@ -367,7 +369,7 @@ __device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo
         const uint32_t key = (lo << 4) | q;
         for (unsigned long long m = kb; m; m &= m - 1ull) {
             const int f = __builtin_ctzll(m);
-            const uint32_t kf = __shfl(key, f);
+            const uint32_t kf = (uint32_t)__builtin_amdgcn_readlane((int)key, f);
             if (kf < key || (kf == key && (uint32_t)f < lane)) rank++;
         }
     }
