@@ -218,6 +218,12 @@ __device__ __forceinline__ void scan_reset(Scan& sc) {
 // Left to the compiler's wait counting, every form of the loop waited for the row just requested somewhere: before a copy of
 // freshly loaded registers at the end of a trip, before an address temporary that shares a register with a destination it
 // believed pending on some path, or at the loop's exit test.
+// What the counted waits rely on (checked in the generated code of this file, and by tests/test_regions_gpu.py on the device):
+// every wave has all 64 lanes (256-thread workgroups, no lane leaves early), so both loads of a request are always issued; the
+// compiler puts no vector memory operation of its own between a request and the wait for the row before it (the row loop has
+// none: no spills -- the kernel needs 38 of the 64 registers its launch bounds allow); and it never copies a row's registers
+// between the request and the wait (two or more register sets with constant indices after unrolling: no copies at the loop's
+// back edge).
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 struct Row { u32x4 x; u32x2 y; };
