@@ -506,18 +506,25 @@ def main():
         ev_join.record(main_s)
 
     # set-up (untimed): one pass with every walk on one stream measures each example's walk time; the walks are then spread
-    # over the walk streams, each onto the least loaded one
+    # over the walk streams
     where = {ex: walk_pool[0] for ex in shards}
     walked = [False]
     launch_all(where)
     torch.cuda.synchronize()
     walked[0] = True
     cost = {ex: shards[ex]["img"].last_kernel_ms(local) for ex in shards}
-    load = [0.0] * len(walk_pool)
-    for ex in layout:
-        k = load.index(min(load))
-        load[k] += cost[ex]
-        where[ex] = walk_pool[k]
+    # list scheduling with release times: a group's walks may start when its region launch has ended (estimated from this pass's
+    # region launches); each walk goes to the stream that can start it first.  Inside a step a walk takes about 1.5 x its time alone.
+    ready, t_acc = [], 0.0
+    for k in range(len(groups)):
+        t_acc += ev_g0[k].elapsed_time(ev_g1[k])
+        ready.append(t_acc)
+    free_at = [0.0] * len(walk_pool)
+    for g_k, grp in enumerate(groups):
+        for ex in grp:
+            k = min(range(len(walk_pool)), key=lambda j: max(free_at[j], ready[g_k]))
+            free_at[k] = max(free_at[k], ready[g_k]) + 1.5 * cost[ex]
+            where[ex] = walk_pool[k]
     order = layout
 
     kernel_ms = {ex: [] for ex in shards}
