@@ -397,7 +397,8 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
                                                              uint64_t* __restrict__ table) {
     const uint32_t lane = threadIdx.x & 63u;
     // the wave's number as a scalar: string offsets and everything derived from them then live in scalar registers
-    const uint64_t wave = (uint64_t)blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = (uint64_t)gridDim.x * 4u;
+    const uint32_t wpb = blockDim.x >> 6;                                // waves per workgroup (4; 1 or 2 as a development variant)
+    const uint64_t wave = (uint64_t)blockIdx.x * wpb + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = (uint64_t)gridDim.x * wpb;
     const uint64_t total16 = (offsets[n] + 15u) & ~(uint64_t)15;        // the batch is readable below this offset
     const uint64_t ymax = total16 - 8u;
     for (uint64_t sid = wave; sid < n; sid += n_waves) {
@@ -446,17 +447,20 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     const char* em = getenv("MFA_REGION_MODE");                   // development knobs
     const int mode = em ? atoi(em) : 0;
     const uint64_t cus = (uint64_t)(n_cus > 0 ? n_cus : 256);
-    uint64_t blocks = (n + 3) / 4;
-    const uint64_t cap = cus * 8u * 64u;                          // beyond this waves take several strings each
+    const char* eb = getenv("MFA_REGION_BLOCK");                  // development: threads per workgroup (64, 128 or 256)
+    const unsigned block = eb && (atoi(eb) == 64 || atoi(eb) == 128) ? (unsigned)atoi(eb) : 256u;
+    const uint64_t wpb = block / 64u;
+    uint64_t blocks = (n + wpb - 1) / wpb;
+    const uint64_t cap = cus * 8u * 64u * (4u / wpb);             // beyond this waves take several strings each
     if (blocks > cap) blocks = cap;
     const char* el = getenv("MFA_REGION_LDS");                    // development: unused dynamic LDS per workgroup, to lower the occupancy
     const unsigned lds = el ? (unsigned)atoi(el) : 0u;
     const char* ed = getenv("MFA_REGION_DEPTH");                  // development: rows per wave in rotation (2, 3 or 4)
     const int depth = ed ? atoi(ed) : kRegionDepth;
-    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 3) hipLaunchKernelGGL((region_scan_kernel<0, 3>), dim3((unsigned)blocks), dim3(256), lds, s, d_bytes, d_offsets, n, d_table);
+    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 3) hipLaunchKernelGGL((region_scan_kernel<0, 3>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
     else return MFA_ERR_UNSUPPORTED;
     HIP_TRY(hipGetLastError());
     return MFA_OK;
