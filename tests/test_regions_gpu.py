@@ -3,6 +3,7 @@ launch-context pool behind the C-ABI's re-entrancy promise (include/mfa_hip.h).
 
 The table is an aid of the walk kernels, so what is checked is what they rely on: every entry is a true
 periodic region, q = 1 entries are exactly the maximal runs, long runs are all there."""
+import os
 import threading
 
 import numpy as np
@@ -240,3 +241,25 @@ def test_shared_region_table_for_several_automata():
         short = [k for k in range(n) if sizes[k] <= 900][:40]
         strings = corpus.host_strings(2, sizes[short], ws[short])
         assert list(own[short].cpu().numpy()) == list(oracle_lib.OracleImage(blob).match(strings)), name
+
+
+def test_bench_line_smoke():
+    """bench.py end to end at a small size: one JSON line with the contract's fields, the roofline and the cpu_baseline objects"""
+    import json
+    import subprocess
+    import sys
+    root = oracle_lib.ROOT
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--strings-per-example", "3000", "--steps", "2", "--warmup", "1",
+                        "--no-secondary"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline", "ranks_seen"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["value"] > 0 and d["dtype"] == "u8"
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["peak"] == 8000.0 and r["region_scan_kernel"]["launches_per_step"] >= 1
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["parity"] is True and c["cores"] >= 1
