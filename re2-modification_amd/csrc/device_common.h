@@ -8,9 +8,11 @@
 #ifndef MFA_DEVICE_COMMON_H
 #define MFA_DEVICE_COMMON_H
 
-// loads in flight per lane in the wave-cooperative scans; the specialised kernels trade depth for registers (occupancy)
+// 16-byte loads in flight per lane and side in the wave-cooperative span comparison.  Two, not eight: eight cost 32 more VGPRs in
+// every kernel (their peak), and inside a step of the headline corpus every register a walk wave does not hold is room for
+// region-pass waves on its SIMD (measured per step: depth 8 4.86 ms, 4 4.79, 2 4.70, 1 4.65).
 #ifndef MFA_SCAN_DEPTH
-#define MFA_SCAN_DEPTH 8
+#define MFA_SCAN_DEPTH 2
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>

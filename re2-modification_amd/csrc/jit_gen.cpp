@@ -545,7 +545,7 @@ struct Gen {
     std::string run() {
         const uint32_t N = g.h.n_nodes;
         std::vector<std::string> words = slot_words();
-        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 8) << "\n#define MFA_RUN_DEPTH " << knob("MFA_GEN_RUN_DEPTH", 2) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
+        o << "// generated by re2-modification_amd/csrc/jit_gen.cpp -- do not edit\n#define MFA_PROBE_PERIODS " << knob("MFA_GEN_PROBE_PERIODS", 5) << "u\n#define MFA_SCAN_DEPTH " << knob("MFA_GEN_SCAN_DEPTH", 2) << "\n#define MFA_RUN_DEPTH " << knob("MFA_GEN_RUN_DEPTH", 2) << "\n#ifndef MFA_STATS_BUILD\n#define MFA_STATS_BUILD 0\n#endif\n" << kPrelude;
         o << "\n#define REV " << (rev ? "true" : "false") << "\n#define N_WORDS " << words.size() << "\n#define N_KEYS " << (N - 1) << "\n\n";
         const bool huge = jit_slot_registers(g) > 272;
         const uint32_t lanes = huge ? huge_lanes((uint32_t)words.size()) : 64u;
