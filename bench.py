@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.join(ROOT, "re2-modification_amd"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PARITY_N = 48                  # strings per example whose GPU answers are re-checked on the CPU after the timed region
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02e_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02f_traffic.json")
 
 
 def spawn_ranks(args):
