@@ -66,6 +66,7 @@ typedef struct mfa_image_info {
 #define MFA_KERNEL_GENERIC     1u /* mfa_walk_kernel: table-driven memory-automaton walk, slots in LDS  */
 #define MFA_KERNEL_SPECIALISED 2u /* mfa_jit_kernel: the same walk generated for one automaton, slots in VGPRs */
 #define MFA_KERNEL_TABLE       3u /* dfa_walk_kernel: tabulated memory-less automaton                    */
+#define MFA_KERNEL_WALK        4u /* walk_kernel: table-driven memory-automaton walk over a list of live states */
 
 /* Build an image from a blob (include/mfa_image_format.h).  Host-only work: parse,
  * check the structural invariants the kernels rely on, and for MFA_KIND_NFA tabulate
@@ -124,6 +125,26 @@ int  mfa_region_scan(const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t
  * (or on a stream this one waits for).  d_table == NULL: no table, every step is executed. */
 int  mfa_match_batch_regions(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                              uint8_t* d_results, const uint64_t* d_table, int device, void* stream);
+
+/* ---- mixed batches --------------------------------------------------------------------------------
+ * ONE batch whose strings belong to several memory automata, segment by segment (the 10-example attack
+ * corpus is one byte buffer, one offset array and ten segments).  Replaces: running the loop of
+ * match.cpp:21-31 once per automaton.  A mixed object holds the automata's tables back to back, per
+ * device; the images must outlive it, scan in the same direction and fit the table-driven walk
+ * (MFA_ERR_UNSUPPORTED otherwise).  One call runs the region pass over the batch in a few groups of
+ * consecutive segments and walks each group -- all its automata in ONE launch, any lane any automaton --
+ * as soon as its regions are known, on internal streams: the walk of a group runs beside the region
+ * pass of the next.  `stream` sees the call as a single operation (it waits for the internal streams). */
+typedef struct mfa_mixed mfa_mixed_t;
+int  mfa_mixed_create(mfa_image_t* const* images, uint32_t n_images, mfa_mixed_t** out);
+void mfa_mixed_destroy(mfa_mixed_t* mx);
+/* seg_first: HOST array of n_images + 1 string indices, seg_first[0] = 0, seg_first[n_images] = n: strings
+ * seg_first[s] .. seg_first[s+1]-1 are matched against images[s].  Device pointers as in mfa_match_batch. */
+int  mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                     const uint64_t* seg_first, uint8_t* d_results, int device, void* stream);
+/* device time of the last mfa_match_mixed call on `device`: its region launches, and first region launch to
+ * last walk (either pointer may be NULL).  Synchronises on the call's last events. */
+int  mfa_mixed_last_ms(mfa_mixed_t* mx, int device, float* region_ms, float* span_ms);
 
 /* Same with HOST pointers: copies the batch to the device, matches, copies the
  * results back, synchronises.  Convenience for callers that hold std::strings

@@ -81,6 +81,7 @@ void device_release(DeviceState& ds) {
     if (ds.d_dfa_trans) (void)hipFree(ds.d_dfa_trans);
     if (ds.d_dfa_accept) (void)hipFree(ds.d_dfa_accept);
     if (ds.d_byte_class) (void)hipFree(ds.d_byte_class);
+    if (ds.d_walk) (void)hipFree(ds.d_walk);
     for (LaunchCtx* cx : ds.ctxs) { ctx_free(*cx); delete cx; }
     jit_unload(ds);
     ds = DeviceState{};
@@ -109,6 +110,7 @@ int device_prepare(mfa_image* img, int device, DeviceState** out) {
     if (h.h.kind == MFA_KIND_MFA) {
         rc = up((void**)&ds.d_edge_begin, h.edge_begin.data(), h.edge_begin.size() * 4);
         if (rc == MFA_OK) rc = up((void**)&ds.d_edges, h.edges.data(), h.edges.size() * sizeof(mfa_blob_edge));
+        if (rc == MFA_OK && img->walk_ok) rc = up((void**)&ds.d_walk, img->walk.words.data(), img->walk.words.size() * 4);
     } else {
         rc = up((void**)&ds.d_dfa_trans, h.dfa_trans.data(), h.dfa_trans.size() * 2);
         if (rc == MFA_OK) rc = up((void**)&ds.d_dfa_accept, h.dfa_accept.data(), h.dfa_accept.size());
@@ -134,6 +136,7 @@ int mfa_image_create(const void* blob, size_t n_bytes, mfa_image_t** out) {
     int rc = parse_blob(blob, n_bytes, img->host);
     if (rc == MFA_OK) rc = img->host.h.kind == MFA_KIND_MFA ? check_mfa_invariants(img->host) : tabulate_nfa(img->host);
     if (rc != MFA_OK) { delete img; return rc; }
+    if (img->host.h.kind == MFA_KIND_MFA) img->walk_ok = build_walk_tables(img->host, img->walk) == MFA_OK;
     *out = img;
     return MFA_OK;
 }
@@ -191,11 +194,31 @@ static int match_impl(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* 
     if (rc != MFA_OK) return rc;
     HIP_TRY(hipSetDevice(device));
     const bool is_mfa = img->host.h.kind == MFA_KIND_MFA;
-    const bool jit = is_mfa && jit_load(img->host, *ds);
+    const bool table_walk = is_mfa && img->walk_ok && walk_selected();
+    const bool jit = is_mfa && !table_walk && jit_load(img->host, *ds);
     LaunchCtx* cx = nullptr;
     rc = ctx_acquire(*ds, stream, &cx);
     if (rc != MFA_OK) return rc;
-    if (jit) {
+    if (table_walk) {
+        img->last_kernel = MFA_KERNEL_WALK;
+        if (own_regions && regions_enabled()) {
+            rc = ctx_reserve((void**)&cx->d_regions, &cx->region_bytes, (size_t)n * MFA_REGION_WORDS * sizeof(uint64_t));
+            if (rc != MFA_OK) return rc;
+            HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_r0, (hipStream_t)stream));
+            rc = launch_region_scan(ds->n_cus, d_bytes, d_offsets, n, cx->d_regions, stream);
+            if (rc != MFA_OK) return rc;
+            HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_r1, (hipStream_t)stream));
+            cx->ran_regions = true;
+            d_table = cx->d_regions;
+        }
+        const WalkPlanInput p{img->walk.K, img->walk.max_live, img->walk.reversed, (uint32_t)img->walk.words.size()};
+        const uint32_t sf[2] = {0u, (uint32_t)n}, stb[1] = {0u};
+        if (n > 0xffffffffull) return MFA_ERR_INVALID_ARG;
+        HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_start, (hipStream_t)stream));
+        rc = launch_walk(p, ds->d_walk, ds->n_cus, d_bytes, d_offsets, n, d_results, d_table, 1u, sf, stb, &cx->d_scratch, &cx->scratch_bytes,
+                         cx->d_counter, stream);
+        HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_stop, (hipStream_t)stream));
+    } else if (jit) {
         img->last_kernel = MFA_KERNEL_SPECIALISED;
         if (own_regions && regions_enabled()) {
             rc = ctx_reserve((void**)&cx->d_regions, &cx->region_bytes, (size_t)n * MFA_REGION_WORDS * sizeof(uint64_t));

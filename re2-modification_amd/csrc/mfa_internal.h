@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/mfa_hip.h"
+#include "walk_tables.h"
 
 namespace mfa {
 
@@ -77,6 +78,8 @@ struct DeviceState {
     int                 jit_waves_per_cu = 0;
     uint32_t            jit_words = 0;         // words per slot set of the specialised kernel
     uint32_t            jit_lanes = 64;        // string-carrying lanes per wave
+    // live-list walk (walk.hip): the image's tables on this device
+    uint32_t*           d_walk = nullptr;
 };
 
 }  // namespace mfa
@@ -86,6 +89,8 @@ struct mfa_image {
     std::mutex                        mu;
     std::map<int, mfa::DeviceState>   dev;
     uint32_t                          last_kernel = 0;   // MFA_KERNEL_*
+    mfa::WalkTables                   walk;              // MFA kind: tables of the live-list walk (walk_tables.h)
+    bool                              walk_ok = false;   //   ... built (false: the automaton exceeds the table format)
 };
 
 namespace mfa {
@@ -113,6 +118,12 @@ void        jit_print_stats(LaunchCtx& cx, const char* tag);
 int         launch_mfa_jit(DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint8_t* d_results,
                            const uint64_t* d_regions, void* stream);
 void device_release(DeviceState& ds);
+// live-list walk (walk_launch.hip).  seg_first: n_seg + 1 string indices relative to the sub-batch; seg_table: word offsets into d_tables
+struct WalkPlanInput { uint32_t K, max_live; bool reversed; uint32_t table_words; };
+int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
+                uint8_t* d_results, const uint64_t* d_regions, uint32_t n_seg, const uint32_t* seg_first, const uint32_t* seg_table,
+                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream);
+bool walk_selected();      // MFA_WALK=table|jit
 void set_last_hip_error(int e);
 
 }  // namespace mfa

@@ -1,0 +1,43 @@
+// Launch interface of the live-list walk kernel (walk.hip, one object per cell count K).
+#ifndef MFA_WALK_H
+#define MFA_WALK_H
+
+#include <cstddef>
+#include <cstdint>
+
+#ifndef WALK_MIN_WAVES
+#define WALK_MIN_WAVES 2      /* __launch_bounds__: waves per SIMD the register allocation leaves room for */
+#endif
+
+namespace mfa {
+
+constexpr uint32_t WALK_MAX_SEG = 16;      // automata per launch
+
+struct WalkArgs {                     // kernel parameters; every pointer is a device pointer
+    const uint8_t*  bytes;
+    const uint64_t* offsets;
+    uint64_t        n;
+    uint8_t*        results;
+    const uint64_t* regions;          // region table of the batch, or nullptr
+    const uint32_t* tables;           // table blocks of the launch's automata, back to back (walk_tables.h)
+    uint32_t*       spill;            // per wave: list entries and probe images beyond the LDS capacity
+    unsigned long long* counter;      // ticket counter, zeroed before the launch
+    uint32_t table_words, shared_words;      // LDS words: the tables, and the tables rounded up to a multiple of 64
+    uint32_t n_seg, C, CX, accel;
+    uint32_t seg_first[WALK_MAX_SEG + 1];    // segment s = strings seg_first[s] .. seg_first[s+1]-1 of this launch ...
+    uint32_t seg_table[WALK_MAX_SEG];        // ... walks the automaton whose table block starts at this word of `tables`
+};
+
+struct WalkLaunch {
+    WalkArgs args;
+    unsigned grid;                    // workgroups of 256 threads
+    bool     reversed;
+};
+
+#define MFA_WALK_DECL(K) int launch_walk_k##K(const WalkLaunch& L, void* stream); size_t walk_wave_words_k##K(uint32_t C);
+MFA_WALK_DECL(1) MFA_WALK_DECL(2) MFA_WALK_DECL(3) MFA_WALK_DECL(4) MFA_WALK_DECL(5) MFA_WALK_DECL(6) MFA_WALK_DECL(7) MFA_WALK_DECL(8) MFA_WALK_DECL(9)
+#undef MFA_WALK_DECL
+
+}  // namespace mfa
+
+#endif

@@ -1,0 +1,99 @@
+// The live-list walk kernel (walk_core.h) for gfx950: one string per lane, 64 strings per wave, 4 waves per workgroup that share
+// one copy of the automaton tables in LDS.  Table driven: nothing is compiled per automaton, and the lanes of one wave may walk
+// DIFFERENT automata (a mixed batch is one launch; mfa_match_mixed).  Compiled once per cell count K (-DWALK_K=1..9).
+//
+// Persistent waves: a launch starts as many workgroups as the device holds (or the batch needs), the first 64 strings of a wave
+// come from its position in the grid, the following ones from a ticket counter.  A lane that finishes its string takes the next
+// ticket while the other lanes of the wave go on.
+#include <hip/hip_runtime.h>
+
+#include "mfa_internal.h"
+#include "walk.h"
+#include "walk_core.h"
+
+#ifndef WALK_K
+#error "compile with -DWALK_K=<cells>"
+#endif
+
+namespace mfa {
+
+using namespace mfa_walk;
+
+struct TicketFeeder {
+    unsigned long long* counter;
+    uint64_t n, first_sid;
+    bool first_round = true;
+    __device__ __forceinline__ bool take(bool want, uint64_t& sid) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const unsigned long long wb = __ballot(want);
+        unsigned long long first = 0;
+        if (first_round) first = first_sid;
+        else {
+            const int leader = __builtin_ctzll(wb);
+            if (lane == (uint32_t)leader) first = atomicAdd(counter, (unsigned long long)__builtin_popcountll(wb));
+            first = ((unsigned long long)__shfl((uint32_t)(first >> 32), leader) << 32) | __shfl((uint32_t)first, leader);
+            first += (unsigned long long)gridDim.x * blockDim.x;
+        }
+        first_round = false;
+        sid = first + (unsigned long long)__builtin_popcountll(wb & ((1ull << lane) - 1ull));
+        return want && sid < n;
+    }
+};
+
+// LDS of a workgroup: [tables] then per wave [lv][ld][sb][sa][rt_cache]
+template <int K, bool REV>
+__global__ void __launch_bounds__(256, WALK_MIN_WAVES)
+walk_kernel(WalkArgs a) {
+    extern __shared__ uint32_t smem[];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t* const T = smem;
+    for (uint32_t k = threadIdx.x; k < a.table_words; k += blockDim.x) T[k] = a.tables[k];
+    __syncthreads();
+    constexpr uint32_t W = Lay<K>::W, DW = Lay<K>::DW;
+    const uint32_t per_wave = a.C * 64u * (3u * W + 3u * DW) + 2u * 64u * MFA_RT_CACHED;
+    uint32_t* base = smem + a.shared_words + wave * per_wave;
+    Store st;
+    st.C = a.C; st.CX = a.CX;
+    st.lv = base + lane; base += 2u * a.C * W * 64u;
+    st.ld = base + lane; base += 2u * a.C * DW * 64u;
+    st.sb = base + lane; base += a.C * W * 64u;
+    st.sa = base + lane; base += a.C * DW * 64u;
+    uint64_t* const rtc = reinterpret_cast<uint64_t*>(base) + lane;
+    const uint64_t gwave = (uint64_t)blockIdx.x * 4u + wave;
+    uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * (3u * W + 3u * DW));
+    st.gv = g + lane; g += 2u * a.CX * W * 64u;
+    st.gd = g + lane; g += 2u * a.CX * DW * 64u;
+    st.gsb = g + lane; g += a.CX * W * 64u;
+    st.gsa = g + lane;
+    Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.n_seg, a.seg_first, a.seg_table};
+    TicketFeeder feed{a.counter, a.n, gwave * 64u};
+    walk_wave<K, REV, TicketFeeder>(b, T, st, rtc, feed, nullptr);
+}
+
+#define WALK_CAT2(a, b) a##b
+#define WALK_CAT(a, b) WALK_CAT2(a, b)
+
+// words of LDS one wave needs at capacity C
+static size_t wave_words(uint32_t C) { return (size_t)C * 64u * (3u * Lay<WALK_K>::W + 3u * Lay<WALK_K>::DW) + 2u * 64u * MFA_RT_CACHED; }
+
+int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
+    WalkArgs a = L.args;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = ((size_t)a.shared_words + 4u * wave_words(a.C)) * 4u;
+    if (lds > 160u * 1024u) return MFA_ERR_UNSUPPORTED;
+    hipError_t e;
+    if (L.reversed) {
+        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, true>), dim3(L.grid), dim3(256), lds, s, a);
+    } else {
+        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, false>), dim3(L.grid), dim3(256), lds, s, a);
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
+    return MFA_OK;
+}
+
+size_t WALK_CAT(walk_wave_words_k, WALK_K)(uint32_t C) { return wave_words(C); }
+
+}  // namespace mfa

@@ -1,0 +1,739 @@
+// The live-list walk: MFA::match (reference mfa.cpp:215-236) for one string per lane, interpreted from tables.
+//
+// Included by walk.hip (the kernel, gfx950, 64 lanes per wave) and by tests/emul/walk_emul.cpp (the same source compiled for the
+// host as a wave of ONE lane: a differential test of the step function and of the jump logic against the oracle that needs no
+// GPU; test infrastructure only, the product path is the kernel).
+//
+// ---- state ------------------------------------------------------------------------------------------------------------
+// mfa.cpp:206-211 evaluates the first state per node in set order and drops the rest, so what lives between two steps is one
+// state per node at most, the minimum under (pos, first cell name, allocation time).  A lane keeps those states as a LIST of
+// entries (lists are short: 2-8 entries on the README automata, whatever the node count), two lists per lane (the step reads
+// one and builds the other) in LDS, [entry][word][lane] so that every lane owns a bank; entries beyond the LDS capacity C
+// spill to a per-wave area in global memory.
+//   entry = P | W1 | per cell: S, L                       (2 + 2K words)
+//     P  = pos << 4 | name of the first cell present      (the set order's leading key, compared as one integer)
+//     W1 = vid | tie << 16                                 vid = the state's vnode (walk_tables.h): node << vb | variant
+//     S  = start | first byte << 24     L = len | flags << 24      the cell value is scan[start, start + len) (cells are spans:
+//          every write appends the text just consumed, mfa.cpp:89-104); flags F_PRESENT | F_OPEN | F_READ | F_UNI
+// Allocation time = creation order (copy_memory allocates a state's cells when the state is created, mfa.cpp:107-114).  Within
+// one step the candidates for a node are created in this order: carried waiting states (they keep their old cells), then the
+// children of states with pos == i in node order, then the children of waiting states in node order; within one source in
+// edge order, depth first.  `tie` encodes the first two levels (0 carried, 1 + node, 1025 + node), the last is the order in
+// which a source's effective edges are listed: a candidate replaces an entry only if (P, tie) is strictly smaller.
+//
+// ---- jumps ------------------------------------------------------------------------------------------------------------
+// Inside a stretch of input that repeats with a short period (the region table of regions.hip) the list usually moves affinely
+// from period to period.  The step exists in two instantiations, on plain values and on dual values (value, change per
+// period; device_common.h): after two periods that moved the list by the same amounts a lane takes one period of dual steps,
+// which yield the next list, where the step map sends the direction, and for how many periods every comparison made keeps its
+// outcome; if the direction reproduced itself the lane adds (periods - 1) * direction and skips those steps.  Exact: a jump is
+// only taken over steps whose every branch outcome is proven.
+#ifndef MFA_WALK_CORE_H
+#define MFA_WALK_CORE_H
+
+#include "../../include/mfa_image_format.h"
+#include "device_common.h"
+
+#ifndef WALK_WV
+#define WALK_WV 64u          /* lanes per wave = stride of the per-lane arrays */
+#endif
+#ifndef WALK_DEV
+#define WALK_DEV __device__ __forceinline__
+#endif
+#ifndef WALK_PROBE_PERIODS
+#define WALK_PROBE_PERIODS 5u
+#endif
+
+namespace mfa_walk {
+
+// vinfo bits (walk_tables.h)
+#define VI_VALID 1u
+#define VI_EPS   2u
+#define VI_CACC  4u
+#define VI_QUAL  8u
+
+#define TIE_CARRY 0u
+#define TIE_HERE  1u
+#define TIE_WAIT  1025u
+
+// ---- wave primitives (one lane on the host) ---------------------------------------------------------------------------------
+#ifdef MFA_HOST_EMUL
+WALK_DEV uint32_t wv_lane() { return 0u; }
+WALK_DEV uint32_t wv_max(uint32_t v) { return v; }
+WALK_DEV uint64_t wv_shfl64(uint64_t v, int) { return v; }
+// the wave-wide scans of device_common.h assume 64 lanes: scalar restatements for the one-lane wave
+template <bool REV>
+inline uint32_t coop_run_end_x(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t) {
+    if (i0 + 1u >= len) return len;
+    auto at = [&](uint32_t j) { return bytes[base + (REV ? (uint64_t)(len - 1u - j) : (uint64_t)j)]; };
+    const uint8_t c = at(i0);
+    uint32_t j = i0 + 1u;
+    while (j < len && at(j) == c) j++;
+    return j;
+}
+inline bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, uint32_t l, uint32_t) {
+    for (uint32_t k = 0; k < l; k++)
+        if (bytes[pa + k] != bytes[pb + k]) return false;
+    return true;
+}
+#else
+WALK_DEV uint32_t wv_lane() { return threadIdx.x & 63u; }
+WALK_DEV uint32_t wv_max(uint32_t v) {          // wave-wide maximum of a small count, as a scalar
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+WALK_DEV uint64_t wv_shfl64(uint64_t v, int L) { return ((uint64_t)__shfl((uint32_t)(v >> 32), L) << 32) | __shfl((uint32_t)v, L); }
+template <bool REV>
+WALK_DEV uint32_t coop_run_end_x(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t lane) { return coop_run_end<REV>(bytes, base, len, i0, lane); }
+WALK_DEV bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, uint32_t l, uint32_t lane) { return coop_mem_equal(bytes, pa, pb, l, lane); }
+#endif
+
+// ---- per-lane view of an automaton's tables ------------------------------------------------------------------------------------
+struct Aut {
+    uint32_t cmap, vinfo, vc, vb, ee;      // word offsets into the table block
+    uint32_t nc, vbits, start;
+};
+WALK_DEV void aut_load(Aut& a, const uint32_t* T, uint32_t at) {
+    a.cmap = at + T[at + 5]; a.vinfo = at + T[at + 6]; a.vc = at + T[at + 7]; a.vb = at + T[at + 8]; a.ee = at + T[at + 9];
+    a.nc = T[at + 2]; a.vbits = T[at + 1]; a.start = T[at + 4];
+}
+
+// ---- list storage -----------------------------------------------------------------------------------------------------------------
+template <int K> struct Lay {
+    static constexpr uint32_t W = 2 + 2 * K;            // value words per entry
+    static constexpr uint32_t DW = (1 + 2 * K + 1) / 2;  // direction words per entry: int16 each (pos, then S, L per cell)
+    static constexpr uint32_t EEW = K <= 6 ? 2 : 3;      // words per effective edge
+};
+
+struct Store {               // all pointers already offset by the lane
+    uint32_t* lv;            // LDS  [2][C][W][WV]    list values
+    uint32_t* ld;            // LDS  [2][C][DW][WV]   list directions (dual steps)
+    uint32_t* sb;            // LDS  [C][W][WV]       the list one period ago
+    uint32_t* sa;            // LDS  [C][DW][WV]      the movement over the last period
+    uint32_t* gv;            // global [2][CX][W][WV]  entries C, C+1, ... of either list
+    uint32_t* gd;            // global [2][CX][DW][WV]
+    uint32_t* gsb;           // global [CX][W][WV]
+    uint32_t* gsa;           // global [CX][DW][WV]
+    uint32_t C, CX;
+};
+
+template <int K> WALK_DEV uint32_t rd_v(const Store& st, uint32_t l, uint32_t e, uint32_t w) {
+    return e < st.C ? st.lv[((l * st.C + e) * Lay<K>::W + w) * WALK_WV] : st.gv[((l * st.CX + (e - st.C)) * Lay<K>::W + w) * WALK_WV];
+}
+template <int K> WALK_DEV void wr_v(const Store& st, uint32_t l, uint32_t e, uint32_t w, uint32_t v) {
+    if (e < st.C) st.lv[((l * st.C + e) * Lay<K>::W + w) * WALK_WV] = v; else st.gv[((l * st.CX + (e - st.C)) * Lay<K>::W + w) * WALK_WV] = v;
+}
+template <int K> WALK_DEV uint32_t rd_d(const Store& st, uint32_t l, uint32_t e, uint32_t w) {
+    return e < st.C ? st.ld[((l * st.C + e) * Lay<K>::DW + w) * WALK_WV] : st.gd[((l * st.CX + (e - st.C)) * Lay<K>::DW + w) * WALK_WV];
+}
+template <int K> WALK_DEV void wr_d(const Store& st, uint32_t l, uint32_t e, uint32_t w, uint32_t v) {
+    if (e < st.C) st.ld[((l * st.C + e) * Lay<K>::DW + w) * WALK_WV] = v; else st.gd[((l * st.CX + (e - st.C)) * Lay<K>::DW + w) * WALK_WV] = v;
+}
+
+// an entry in registers
+template <class U, int K> struct Ent { U P; uint32_t vid; U S[K], L[K]; uint32_t F[K]; };
+
+WALK_DEV int32_t d16(uint32_t w, uint32_t k) { return (int32_t)(int16_t)(uint16_t)(w >> (16u * (k & 1u))); }
+WALK_DEV void setv(uint32_t& x, uint32_t v) { x = v; }
+WALK_DEV void setv(Dual& x, uint32_t v) { x.v = v; x.d = 0; }
+
+template <int K> WALK_DEV void load_dirs(const Store&, uint32_t, uint32_t, bool, Ent<uint32_t, K>&) {}
+template <int K> WALK_DEV void load_dirs(const Store& st, uint32_t l, uint32_t e, bool want, Ent<Dual, K>& x) {
+    uint32_t w[Lay<K>::DW];
+#pragma unroll
+    for (uint32_t k = 0; k < Lay<K>::DW; k++) w[k] = want ? rd_d<K>(st, l, e, k) : 0u;
+    x.P.d = d16(w[0], 0) * 16;
+#pragma unroll
+    for (int c = 0; c < K; c++) { x.S[c].d = d16(w[(1 + 2 * c) / 2], 1 + 2 * c); x.L[c].d = d16(w[(2 + 2 * c) / 2], 2 + 2 * c); }
+}
+// direction of the key of an entry only
+template <int K> WALK_DEV void load_pdir(const Store&, uint32_t, uint32_t, bool, uint32_t&) {}
+template <int K> WALK_DEV void load_pdir(const Store& st, uint32_t l, uint32_t e, bool want, Dual& P) { P.d = want ? d16(rd_d<K>(st, l, e, 0), 0) * 16 : 0; }
+
+// want_d: the lane's directions are meaningful (it is in its dual period); other lanes carry direction 0
+template <class U, int K> WALK_DEV void load_entry(const Store& st, uint32_t l, uint32_t e, bool want_d, Ent<U, K>& x) {
+    uint32_t w[Lay<K>::W];
+#pragma unroll
+    for (uint32_t k = 0; k < Lay<K>::W; k++) w[k] = rd_v<K>(st, l, e, k);
+    setv(x.P, w[0]);
+    x.vid = w[1] & 0xffffu;
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        setv(x.S[c], w[2 + 2 * c] & 0x00ffffffu);
+        setv(x.L[c], w[3 + 2 * c] & 0x00ffffffu);
+        x.F[c] = ((w[3 + 2 * c] >> 24) & 0xfu) | ((w[2 + 2 * c] >> 24) << 8);
+    }
+    load_dirs<K>(st, l, e, want_d, x);
+}
+
+template <int K> WALK_DEV void store_dirs(const Store&, uint32_t, uint32_t, const Ent<uint32_t, K>&, bool&) {}
+template <int K> WALK_DEV void store_dirs(const Store& st, uint32_t l, uint32_t e, const Ent<Dual, K>& x, bool& fits) {
+    int32_t d[2 * Lay<K>::DW];
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * Lay<K>::DW; k++) d[k] = 0;
+    d[0] = x.P.d / 16;
+    bool ok = (x.P.d & 15) == 0;
+#pragma unroll
+    for (int c = 0; c < K; c++) { d[1 + 2 * c] = x.S[c].d; d[2 + 2 * c] = x.L[c].d; }
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * Lay<K>::DW; k++) ok = ok && d[k] == (int32_t)(int16_t)d[k];
+    if (!ok) fits = false;
+#pragma unroll
+    for (uint32_t k = 0; k < Lay<K>::DW; k++) wr_d<K>(st, l, e, k, ((uint32_t)d[2 * k] & 0xffffu) | ((uint32_t)d[2 * k + 1] << 16));
+}
+
+template <class U, int K> WALK_DEV void store_entry(const Store& st, uint32_t l, uint32_t e, const Ent<U, K>& x, uint32_t tie, bool& fits) {
+    wr_v<K>(st, l, e, 0, val(x.P));
+    wr_v<K>(st, l, e, 1, x.vid | (tie << 16));
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        wr_v<K>(st, l, e, 2 + 2 * c, (val(x.S[c]) & 0x00ffffffu) | ((x.F[c] >> 8) << 24));
+        wr_v<K>(st, l, e, 3 + 2 * c, (val(x.L[c]) & 0x00ffffffu) | ((x.F[c] & 0xfu) << 24));
+    }
+    store_dirs<K>(st, l, e, x, fits);
+}
+
+// ---- memory actions (MFA::doMemoryWriteActions, mfa.cpp:80-105) on one cell; the text just consumed is scan[ts, ts + tl) ------------
+template <class U> WALK_DEV void cell_open(U& S, U& L, uint32_t& F, U ts, U tl, bool tuni, uint32_t tch) {
+    S = ts; L = tl; F = F_PRESENT | F_OPEN | (tuni ? F_UNI : 0u) | (tch << 8);               // create if absent, open(), write(t)
+}
+template <class U> WALK_DEV void cell_write(U& S, U& L, uint32_t& F, U ts, U tl, bool tuni, uint32_t tch, tb_t& TB) {
+    const uint32_t f = F;                                                                      // write(t) when open
+    const bool w = (f & (F_PRESENT | F_OPEN)) == (F_PRESENT | F_OPEN) && !eq(tl, konst<U>(0u), TB);
+    if (!w) return;
+    const bool was_empty = eq(L, konst<U>(0u), TB);
+    const uint32_t fch = (f >> 8) & 0xffu;
+    const bool uni = was_empty ? tuni : ((f & F_UNI) && tuni && fch == tch);
+    S = sel(was_empty, ts, S);
+    L = add(L, tl);
+    F = (f & (F_PRESENT | F_OPEN | F_READ)) | (uni ? F_UNI : 0u) | ((was_empty ? tch : fch) << 8);
+}
+
+// the actions of an edge on the lanes in `pred` (t is a private copy of those lanes' cells)
+template <class U, int K>
+WALK_DEV void apply_actions(Ent<U, K>& t, uint32_t actions, bool pred, U ts, U tl, bool tuni, uint32_t tch, tb_t& TB) {
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        const uint32_t a = (actions >> (2 * c)) & 3u;
+        if (pred) {
+            if (a == MFA_ACT_OPEN) cell_open<U>(t.S[c], t.L[c], t.F[c], ts, tl, tuni, tch);
+            else if (a == MFA_ACT_CLOSE) t.F[c] &= ~F_OPEN;                                  // close(); an absent cell stays absent
+            else cell_write<U>(t.S[c], t.L[c], t.F[c], ts, tl, tuni, tch, TB);
+        }
+    }
+}
+
+// ---- a cell read (mfa.cpp:177-191) on the lanes in `rd`: does scan[i, i + |v|) equal the value? ----------------------------------------
+// Run extents and byte-wise comparisons are done by the whole wave, one lane's at a time (device_common.h).
+template <bool REV, class U>
+WALK_DEV bool cell_read(Input& in, bool rd, U i, uint32_t ch, U vs, U vl, uint32_t vf, tb_t& TB) {
+    const uint32_t lane = wv_lane();
+    {
+        bool nr = rd && uni_needs_run(in, val(i), ch, val(vl), vf);
+        if (nr && in.rt != nullptr) {                    // the region pass knows every long run
+            uint32_t rh;
+            if (rt_run<REV>(in, val(i), rh) || run_end_bounded<REV>(in, val(i), ch, 192u, rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }
+        }
+        for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {
+            const int L = __builtin_ctzll(sb);
+            const uint32_t r = coop_run_end_x<REV>(in.bytes, wv_shfl64(in.base, L), __shfl(in.len, L), __shfl(val(i), L), lane);
+            if (lane == (uint32_t)L) {
+                in.run_lo = val(i); in.run_hi = r; in.run_ch = ch;
+                // a run is a periodic region too (unless one that reaches at least as far is known: a probe may rely on it)
+                if (!(in.per_q != 0u && in.per_lo <= val(i) && val(i) < in.per_hi && in.per_hi >= r)) { in.per_lo = val(i); in.per_hi = r; in.per_q = 1u; }
+            }
+        }
+    }
+    bool ok = false, cmp = false;
+    if (rd) ok = read_pre_u<REV, U>(in, i, ch, vs, vl, vf, TB, cmp);
+    for (unsigned long long sb = __ballot(cmp); sb; sb &= sb - 1ull) {
+        const int L = __builtin_ctzll(sb);
+        const uint32_t ca = val(vs), cb = val(i), cl = val(vl);
+        const uint64_t pa = in.base + (REV ? (uint64_t)(in.len - ca - cl) : (uint64_t)ca), pb = in.base + (REV ? (uint64_t)(in.len - cb - cl) : (uint64_t)cb);
+        const bool r = coop_mem_equal_x(in.bytes, wv_shfl64(pa, L), wv_shfl64(pb, L), __shfl(cl, L), lane);
+        if (lane == (uint32_t)L) ok = r;
+    }
+    return ok;
+}
+
+// ---- the step --------------------------------------------------------------------------------------------------------------------------
+template <class U, int K>
+struct StepCtx {
+    const Store& st;
+    uint32_t nxt;            // the list being built
+    uint32_t n_next;         // per lane: entries in it
+    bool dual_lane;          // per lane: directions are meaningful
+    bool fits;               // per lane: every direction stored so far fits 16 bits
+    tb_t TB;
+};
+
+// candidate (P, tie, cells of t) for the node of `vid` on the lanes in `pred`
+template <class U, int K>
+WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits, U P, uint32_t tie, Ent<U, K>& t) {
+    const uint32_t node = vid >> vbits;
+    uint32_t at = ~0u, w1 = 0;
+    const uint32_t most = wv_max(pred ? cx.n_next : 0u);
+    for (uint32_t j = 0; j < most; j++) {                        // is there an entry for this node already?
+        const bool look = pred && j < cx.n_next;
+        const uint32_t x = look ? rd_v<K>(cx.st, cx.nxt, j, 1) : 0u;
+        if (look && ((x & 0xffffu) >> vbits) == node) { at = j; w1 = x; }
+    }
+    bool win = pred;
+    if (pred && at != ~0u) {
+        U old;
+        setv(old, rd_v<K>(cx.st, cx.nxt, at, 0));
+        load_pdir<K>(cx.st, cx.nxt, at, cx.dual_lane, old);
+        win = lt(P, old, cx.TB) || (eq(P, old, cx.TB) && tie < (w1 >> 16));
+    }
+    if (win) {
+        if (at == ~0u) at = cx.n_next++;
+        t.P = P; t.vid = vid;
+        store_entry<U, K>(cx.st, cx.nxt, at, t, tie, cx.fits);
+    }
+}
+
+template <int K>
+WALK_DEV void ee_decode(const uint32_t* T, uint32_t at, bool p, uint32_t& e0, uint32_t& actions, uint32_t& cm, uint32_t& com, uint32_t& rdm) {
+    e0 = p ? T[at] : 0u;
+    const uint32_t e1 = p ? T[at + 1] : 0u;
+    if (Lay<K>::EEW == 2) {
+        actions = e1 & 0xfffu; cm = (e1 >> 12) & 0x3fu; com = (e1 >> 18) & 0x3fu; rdm = (e1 >> 24) & 0x3fu;
+    } else {
+        const uint32_t e2 = p ? T[at + 2] : 0u;
+        actions = e1 & 0x3ffffu; cm = (e1 >> 18) & 0x1ffu; com = e2 & 0x1ffu; rdm = (e2 >> 9) & 0x1ffu;
+    }
+}
+
+// the state an effective edge starts from: the entry's cells, the cells created on the way (empty, at the entry's pos:
+// mfa.cpp:151-158) and the is_read marks earlier read attempts of this evaluation have left
+template <class U, int K>
+WALK_DEV void frame_state(const Ent<U, K>& E, U pos, uint32_t cm, uint32_t com, uint32_t rdm, Ent<U, K>& s) {
+#pragma unroll
+    for (int c = 0; c < K; c++) {
+        const bool created = (cm >> c) & 1u;
+        s.S[c] = sel(created, pos, E.S[c]);
+        s.L[c] = sel(created, konst<U>(0u), E.L[c]);
+        s.F[c] = created ? (F_PRESENT | F_UNI | (((com >> c) & 1u) ? F_OPEN : 0u)) : E.F[c];
+        if ((rdm >> c) & 1u) s.F[c] |= F_READ;
+    }
+}
+
+// One MFA::evaluateStates call (mfa.cpp:203-213) for every active lane: reads list `cur` (n_cur entries), builds the other one.
+template <class U, int K, bool REV>
+WALK_DEV void walk_step(const Store& st, const uint32_t* T, const Aut& au, Input& in, uint32_t cur, uint32_t n_cur, uint32_t& n_next,
+                        const U i, const U len, const uint32_t ch, const bool final_pass, const bool active, const bool dual_lane,
+                        bool& accept, bool& fits, tb_t& TB) {
+    StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB};
+    const uint32_t cls = (active && !final_pass) ? (T[au.cmap + ((ch & 0xffu) >> 2)] >> (8u * (ch & 3u))) & 0xffu : 0u;
+    const uint32_t most = wv_max(active ? n_cur : 0u);
+    for (uint32_t e = 0; e < most; e++) {
+        const bool have = active && e < n_cur;
+        Ent<U, K> E;
+        load_entry<U, K>(st, cur, have ? e : 0u, dual_lane && have, E);
+        const U pos = have ? posof(E.P, cx.TB) : konst<U>(0u);
+        bool live = have && ge(pos, i, cx.TB);                       // a state the scan has passed does nothing (but it held its node)
+        if (REV) {                                                   // mfa.cpp:116-133
+            if (live) {
+                U need = konst<U>(0u);
+#pragma unroll
+                for (int c = 0; c < K; c++)
+                    if ((E.F[c] & F_PRESENT) && ((E.F[c] & F_OPEN) || !(E.F[c] & F_READ))) need = add(need, E.L[c]);
+                live = le(need, sub(len, i), cx.TB);
+            }
+        }
+        const bool here = live && !final_pass && eq(pos, i, cx.TB);
+        const bool wait = live && !final_pass && !here;
+        const uint32_t vi = have ? T[au.vinfo + E.vid] : 0u;
+        const uint32_t node = E.vid >> au.vbits;
+        // an epsilon edge: the state reaches `finish`, which keeps it iff pos == len (mfa.cpp:138-147); accepting is sticky
+        if ((vi & VI_EPS) && live && !accept && eq(pos, len, cx.TB)) accept = true;
+        {   // a waiting state goes back into the set as it is (mfa.cpp:195-197): older than everything created in this step
+            const bool carry = wait && (vi & VI_QUAL) != 0u;
+            if (__any(carry)) { Ent<U, K> t = E; insert<U, K>(cx, carry, E.vid, au.vbits, E.P, TIE_CARRY, t); }
+        }
+        // ---- the state at pos == i consumes (mfa.cpp:161-194)
+        if (__any(here)) {
+            const uint32_t bl = here ? T[au.vb + E.vid * au.nc + cls] : 0u;
+            const uint32_t bbeg = bl >> 12, bcnt = bl & 0xfffu, bmost = wv_max(bcnt);
+            for (uint32_t j = 0; j < bmost; j++) {
+                const bool p = here && j < bcnt;
+                uint32_t e0, actions, cm, com, rdm;
+                ee_decode<K>(T, au.ee + (bbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
+                const uint32_t tvid = e0 >> 9, tfn = (e0 >> 5) & 15u, cell = (e0 >> 1) & 15u;
+                Ent<U, K> s;
+                frame_state<U, K>(E, pos, cm, com, rdm, s);
+                const bool lit = p && (e0 & 1u) == 0u, rd = p && (e0 & 1u) != 0u;
+                if (__any(lit)) {                                    // a letter (or dot) edge takes the byte (mfa.cpp:171-175)
+                    Ent<U, K> t = s;
+                    apply_actions<U, K>(t, actions, lit, i, konst<U>(1u), true, ch, cx.TB);
+                    insert<U, K>(cx, lit, tvid, au.vbits, mkp(add(i, konst<U>(1u)), tfn), TIE_HERE + node, t);
+                }
+                if (__any(rd)) {                                     // a cell edge reads the cell's value (mfa.cpp:176-191)
+                    Ent<U, K> t = s;                                 // the copy is taken before read() marks the source (mfa.cpp:167 / 177)
+                    U vs = konst<U>(0u), vl = konst<U>(0u);
+                    uint32_t vf = 0u;
+#pragma unroll
+                    for (int c = 0; c < K; c++)
+                        if ((uint32_t)c == cell) { vs = s.S[c]; vl = s.L[c]; vf = s.F[c]; }
+                    const bool ok = cell_read<REV, U>(in, rd, i, ch, vs, vl, vf, cx.TB);
+                    if (__any(ok)) {
+                        apply_actions<U, K>(t, actions, ok, i, vl, (vf & F_UNI) != 0u, (vf >> 8) & 0xffu, cx.TB);
+                        insert<U, K>(cx, ok, tvid, au.vbits, mkp(add(i, vl), tfn), TIE_HERE + node, t);
+                    }
+                }
+            }
+        }
+        // ---- a waiting state (and, in the final pass, a state at pos == len) only follows edges of absent cells (mfa.cpp:148-160)
+        const bool late = live && !here;
+        if ((vi & VI_CACC) && late && !accept && eq(pos, len, cx.TB)) accept = true;
+        if (__any(wait)) {
+            const uint32_t cl = wait ? T[au.vc + E.vid] : 0u;
+            const uint32_t cbeg = cl >> 12, ccnt = cl & 0xfffu, cmost = wv_max(ccnt);
+            for (uint32_t j = 0; j < cmost; j++) {
+                const bool p = wait && j < ccnt;
+                uint32_t e0, actions, cm, com, rdm;
+                ee_decode<K>(T, au.ee + (cbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
+                Ent<U, K> t;
+                frame_state<U, K>(E, pos, cm, com, 0u, t);
+                insert<U, K>(cx, p, e0 >> 9, au.vbits, mkp(pos, (e0 >> 5) & 15u), TIE_WAIT + node, t);
+            }
+        }
+    }
+    n_next = cx.n_next; fits = cx.fits; TB = cx.TB;
+}
+
+// ---- the list one period ago (SB) and its movement (SA) ----------------------------------------------------------------------------------
+template <int K> WALK_DEV uint32_t sb_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.C ? st.sb[(e * Lay<K>::W + w) * WALK_WV] : st.gsb[((e - st.C) * Lay<K>::W + w) * WALK_WV]; }
+template <int K> WALK_DEV void sb_wr(const Store& st, uint32_t e, uint32_t w, uint32_t v) {
+    if (e < st.C) st.sb[(e * Lay<K>::W + w) * WALK_WV] = v; else st.gsb[((e - st.C) * Lay<K>::W + w) * WALK_WV] = v;
+}
+template <int K> WALK_DEV uint32_t sa_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.C ? st.sa[(e * Lay<K>::DW + w) * WALK_WV] : st.gsa[((e - st.C) * Lay<K>::DW + w) * WALK_WV]; }
+template <int K> WALK_DEV void sa_wr(const Store& st, uint32_t e, uint32_t w, uint32_t v) {
+    if (e < st.C) st.sa[(e * Lay<K>::DW + w) * WALK_WV] = v; else st.gsa[((e - st.C) * Lay<K>::DW + w) * WALK_WV] = v;
+}
+
+// index of a value word's direction: 0 = P (in units of 16), 1 + 2c = S of cell c, 2 + 2c = L of cell c; word 1 has none
+WALK_DEV int dir_index(uint32_t w) { return w == 0u ? 0 : (int)w - 1; }
+
+// save list `cur` of the lanes in `pred`
+template <int K> WALK_DEV void image_save(const Store& st, uint32_t cur, bool pred, uint32_t n) {
+    const uint32_t most = wv_max(pred ? n : 0u);
+    for (uint32_t e = 0; e < most; e++)
+        if (pred && e < n) {
+#pragma unroll
+            for (uint32_t w = 0; w < Lay<K>::W; w++) { const uint32_t v = rd_v<K>(st, cur, e, w); sb_wr<K>(st, e, w, w == 1u ? (v & 0xffffu) : v); }
+        }
+}
+
+// a period boundary on the lanes in `pred`: movement of the list since the image was taken -> SA, list -> SB.
+// moved: the movement differs from the one before; wide: a movement does not fit 16 bits; vac: other nodes than a period ago
+template <int K> WALK_DEV void image_measure(const Store& st, uint32_t cur, bool pred, uint32_t n, uint32_t sb_n, bool& moved, bool& wide, bool& vac) {
+    moved = wide = vac = false;
+    if (pred && n != sb_n) { moved = true; vac = true; }
+    const uint32_t most = wv_max(pred ? n : 0u);
+    for (uint32_t e = 0; e < most; e++)
+        if (pred && e < n) {
+            int32_t d[2 * Lay<K>::DW];
+#pragma unroll
+            for (uint32_t k = 0; k < 2 * Lay<K>::DW; k++) d[k] = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < Lay<K>::W; w++) {
+                uint32_t v = rd_v<K>(st, cur, e, w);
+                if (w == 1u) v &= 0xffffu;
+                const uint32_t b = sb_rd<K>(st, e, w);
+                sb_wr<K>(st, e, w, v);
+                if (w == 1u) { if (v != b) { vac = true; moved = true; } continue; }
+                int32_t dv = (int32_t)(v - b);
+                if (w == 0u) { if (dv & 15) wide = true; dv >>= 4; }
+                d[dir_index(w)] = dv;
+                if (dv != (int32_t)(int16_t)dv) wide = true;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < Lay<K>::DW; k++) {
+                const uint32_t nw = ((uint32_t)d[2 * k] & 0xffffu) | ((uint32_t)d[2 * k + 1] << 16);
+                if (e >= sb_n || nw != sa_rd<K>(st, e, k)) moved = true;
+                sa_wr<K>(st, e, k, nw);
+            }
+        }
+}
+
+// the lanes in `pred` start their dual period: the list's directions are the movement just measured
+template <int K> WALK_DEV void image_dirs(const Store& st, uint32_t cur, bool pred, uint32_t n) {
+    const uint32_t most = wv_max(pred ? n : 0u);
+    for (uint32_t e = 0; e < most; e++)
+        if (pred && e < n) {
+#pragma unroll
+            for (uint32_t k = 0; k < Lay<K>::DW; k++) wr_d<K>(st, cur, e, k, sa_rd<K>(st, e, k));
+        }
+}
+
+// after the dual period: did the list move by exactly SA again, and was SA mapped to itself?
+template <int K> WALK_DEV bool image_same(const Store& st, uint32_t cur, bool pred, uint32_t n, uint32_t sb_n) {
+    bool same = pred && n == sb_n;
+    const uint32_t most = wv_max(same ? n : 0u);
+    for (uint32_t e = 0; e < most; e++)
+        if (same && e < n) {
+            uint32_t differs = 0u;
+            int32_t dv[2 * Lay<K>::DW];
+#pragma unroll
+            for (uint32_t k = 0; k < 2 * Lay<K>::DW; k++) dv[k] = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < Lay<K>::W; w++) {
+                uint32_t v = rd_v<K>(st, cur, e, w);
+                const uint32_t b = sb_rd<K>(st, e, w);
+                if (w == 1u) { differs |= (v & 0xffffu) ^ b; continue; }
+                int32_t m = (int32_t)(v - b);
+                if (w == 0u) { differs |= (uint32_t)(m & 15); m >>= 4; }
+                dv[dir_index(w)] = m;
+                if (m != (int32_t)(int16_t)m) differs |= 1u;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < Lay<K>::DW; k++) {
+                const uint32_t sa = sa_rd<K>(st, e, k);
+                differs |= sa ^ rd_d<K>(st, cur, e, k);                                                   // the direction was mapped to itself
+                differs |= sa ^ (((uint32_t)dv[2 * k] & 0xffffu) | ((uint32_t)dv[2 * k + 1] << 16));      // the list moved by it again
+            }
+            if (differs) same = false;
+        }
+    return same;
+}
+
+// list += skip * direction
+template <int K> WALK_DEV void image_advance(const Store& st, uint32_t cur, bool pred, uint32_t n, uint32_t skip) {
+    const uint32_t most = wv_max(pred ? n : 0u);
+    for (uint32_t e = 0; e < most; e++)
+        if (pred && e < n) {
+            uint32_t dw[Lay<K>::DW];
+#pragma unroll
+            for (uint32_t k = 0; k < Lay<K>::DW; k++) dw[k] = rd_d<K>(st, cur, e, k);
+#pragma unroll
+            for (uint32_t w = 0; w < Lay<K>::W; w++) {
+                if (w == 1u) continue;
+                const int k = dir_index(w);
+                const int32_t d = d16(dw[k / 2], (uint32_t)k) * (w == 0u ? 16 : 1);
+                wr_v<K>(st, cur, e, w, rd_v<K>(st, cur, e, w) + skip * (uint32_t)d);
+            }
+        }
+}
+
+// ---- one wave ------------------------------------------------------------------------------------------------------------------------------
+struct Batch {
+    const uint8_t* bytes;
+    const uint64_t* offsets;
+    uint64_t n;
+    uint8_t* results;
+    const uint64_t* regions;     // region table (regions.hip) or nullptr
+    uint32_t accel;
+    uint32_t n_seg;              // segments of the batch: strings seg_first[s] .. seg_first[s+1]-1 belong to the automaton whose tables
+    const uint32_t* seg_first;   //   start at word seg_table[s] of the table block (n_seg + 1 / n_seg entries, 32-bit string indices)
+    const uint32_t* seg_table;
+};
+
+struct WaveStats { unsigned long long iters = 0, dual = 0, skipped = 0, probes = 0, hits = 0, steps = 0, spills = 0; unsigned long long hist[80] = {0}; };
+
+// Feeder::take(want, sid): hands the next string index to every lane that wants one; returns false when the batch is exhausted
+template <int K, bool REV, class Feeder>
+WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint64_t* rt_cache, Feeder& feed, WaveStats* stats) {
+    Input in;
+    in.bytes = b.bytes; in.total16 = (b.offsets[b.n] + 15u) & ~(uint64_t)15;
+    input_reset(in, 0, 0);
+    in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;
+    bool active = false, exhausted = false, accept = false;
+    uint32_t i = 0, len = 0; uint64_t sid = 0;
+    // probes: phase 0 idle, 1 = plain periods after saving the list, 2 = the dual period
+    uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1, nper = 0;
+    tb_t TBacc = tb_init();
+    bool fits = true, stable = false, patient = false;
+    uint32_t cur = 0, n_cur = 0, sb_n = 0, warm = 0, turn = 0;
+    Aut au;
+    aut_load(au, T, 0u);
+    for (;;) {
+        {   // hand strings to idle lanes
+            const bool want = !active && !exhausted;
+            if (__any(want)) {
+                uint64_t s = 0;
+                const bool got = feed.take(want, s);
+                if (want) {
+                    if (!got) exhausted = true;
+                    else {
+                        sid = s;
+                        uint4 rta, rtb;
+                        rt_fetch(b.regions, sid, rta, rtb);          // the table row and the offsets travel together
+                        const uint64_t o0 = b.offsets[sid], o1 = b.offsets[sid + 1];
+                        if (o1 - o0 > MFA_DEV_MAX_LEN) b.results[sid] = 2;
+                        else {
+                            len = (uint32_t)(o1 - o0);
+                            input_reset(in, o0, len);
+                            rt_attach(in, b.regions, sid, rt_cache, WALK_WV, warm, rta, rtb);
+                            uint32_t seg = 0;
+                            for (uint32_t k = 1; k < b.n_seg; k++)
+                                if (sid >= b.seg_first[k]) seg = k;
+                            aut_load(au, T, b.n_seg ? b.seg_table[seg] : 0u);
+                            i = 0; accept = false; active = true; phase = 0; probe_at = 0; backoff = 8; pp = 1; fails = 0; mult = 1; nper = 0;
+                            stable = false; patient = false;
+                            n_cur = 1;                                // the list: (pos 0, start, no cells)  mfa.cpp:217-219
+                            Ent<uint32_t, K> e0;
+                            e0.P = 0u; e0.vid = au.start;
+#pragma unroll
+                            for (int c = 0; c < K; c++) { e0.S[c] = 0u; e0.L[c] = 0u; e0.F[c] = 0u; }
+                            bool f2 = true;
+                            store_entry<uint32_t, K>(st, cur, 0u, e0, 0u, f2);
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(active)) break;
+        if (stats) stats->iters++;
+        const bool final_pass = (i == len);
+        uint32_t ch = 0x100u;
+        if (turn == 0u) window_turn<REV>(in, i, active && !final_pass);      // the byte windows of all lanes are renewed together
+        if (active && !final_pass) ch = stream_byte<REV>(in, i, 16u - turn);
+        turn = (turn + 1u) & 15u;
+        // ---- does this lane sit at the start of a stretch that repeats?  (probes run in epochs: all lanes that probe do it together)
+        uint32_t q = 0u;
+        const bool ep_busy = __any(phase != 0u);
+        if (b.accel && active && !final_pass && phase == 0u && i >= probe_at && !ep_busy) {
+            if (in.per_q != 0u && in.per_lo <= i && i < in.per_hi) q = in.per_q;      // still inside the region found last
+            else if (in.rt != nullptr) {
+                uint32_t rl, rh, rq, rn;
+                if (rt_find<REV>(in, i, mult, rl, rh, rq, rn)) {
+                    if (in.per_q != 0u) { in.prev_lo = in.per_lo; in.prev_hi = in.per_hi; in.prev_q = in.per_q; }
+                    in.per_lo = rl; in.per_hi = rh; in.per_q = rq; q = rq;
+                } else probe_at = rn;                                        // look again where the next region starts (never, if there is none)
+            } else probe_at = ~0u;                                           // no table: every step is executed
+        }
+        if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }
+        if (q != 0u && q * mult > 16u) mult = 1u;
+        const unsigned long long cand = __ballot(q != 0u && in.per_hi - i >= 4u * q * mult + 24u);
+        const uint32_t ep_pp = cand ? __shfl(q * mult, __builtin_ctzll(cand)) : 0u;      // the first candidate's period leads the epoch
+        {
+            bool begin = false;
+            if (q != 0u) {
+                pp = ep_pp;
+                if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * pp + 24u) {
+                    begin = true; phase = 1u; pk = 0u; nper = 0u; stable = false; sb_n = n_cur;
+                    if (stats) stats->probes++;
+                } else if (in.per_hi - i < 4u * q * mult + 24u) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // too short to be worth a probe
+                else probe_at = i + 1u;                                                                                  // does not fit this epoch's period
+            }
+            if (__any(begin)) image_save<K>(st, cur, begin, n_cur);
+        }
+        uint32_t n_next = 0;
+        tb_t TB = tb_init();
+        const bool p2 = phase == 2u;
+        if (__any(p2)) {
+            // dual step: lanes in their dual period carry the list's directions, the others direction 0 (their TB is ignored)
+            if (stats) stats->dual++;
+            const Dual di{i, (int32_t)pp}, dlen{len, 0};
+            in.dual_p = p2 ? pp : 0u;
+            (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the region
+            (void)eq(di, dlen, TB);
+            walk_step<Dual, K, REV>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB);
+            in.dual_p = 0u;
+        } else {
+            bool f2 = true;
+            walk_step<uint32_t, K, REV>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB);
+        }
+        cur ^= 1u;
+        if (active) n_cur = n_next;
+        const bool any_next = n_next != 0u;
+        if (stats && active && n_cur > st.C) stats->spills++;
+#ifdef MFA_HOST_EMUL
+        if (stats && active) stats->hist[n_cur < 79u ? n_cur : 79u]++;
+#endif
+        uint32_t skip = 0;
+        if (p2) {
+            tb_min(TBacc, TB.a, TB.b);
+            pk++;
+            bool ended = false;
+            if (pk == pp) {
+                const int64_t periods = tb_steps(TBacc);
+                bool same = !accept && any_next && periods > 1 && fits;
+                ended = true;
+                // (the comparison below is wave-level code: done after this block)
+                if (!same) ended = true;
+                phase = same ? 3u : 0u;                              // 3: the comparison with the image decides
+            } else if (tb_is_one(TBacc) || accept || !any_next) {
+                phase = 0u; fails++;                                 // cannot succeed any more: stop the probe here
+                if (nper == 1u && !patient && pp > 2u) patient = true; else mult = mult % 8u + 1u;
+                if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }
+            }
+            (void)ended;
+        }
+        if (__any(phase == 3u)) {
+            const bool same = image_same<K>(st, cur, phase == 3u, n_cur, sb_n);
+            if (phase == 3u) {
+                if (same) {
+                    const int64_t periods = tb_steps(TBacc);
+                    skip = (uint32_t)(periods - 1 < (int64_t)0x00ffffff ? periods - 1 : (int64_t)0x00ffffff);
+                }
+                phase = 0u;
+            }
+        }
+        if (p2 && pk == pp && phase == 0u) {
+            if (skip) { backoff = 8u; fails = 0u; if (stats) { stats->hits++; stats->skipped += (unsigned long long)skip * pp; } }
+            else {
+                // a failed dual period: after an optimistic start (one plain period) the next probe of this string waits for two equal
+                // movements; otherwise the list may repeat with a multiple of the period
+                fails++;
+                if (nper == 1u && !patient && pp > 2u) patient = true; else mult = mult % 8u + 1u;
+                if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }
+            }
+        }
+        if (__any(skip != 0u)) image_advance<K>(st, cur, skip != 0u, n_cur, skip);
+        if (skip) { i += skip * pp; input_drop_window(in); probe_at = i + 1u + pp; }
+        else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);
+        if (phase == 1u) pk++;
+        // plain periods of a probe: after each one the movement of the list over the period is compared with the previous period's; a
+        // lane is ready for the dual period once two consecutive movements agree.  All lanes of an epoch reach their period
+        // boundaries in the same iteration and go on together.
+        {
+            const bool at_end = phase == 1u && pk == pp;
+            if (__any(at_end)) {
+                bool moved, wide, vac;
+                image_measure<K>(st, cur, at_end, n_cur, sb_n, moved, wide, vac);
+                if (at_end) {
+                    const bool eqd = nper != 0u && !moved;
+                    const bool occ = nper == 0u && !patient && pp > 2u && !vac;      // first period: the same nodes before and after it
+                    fits = !wide;
+                    sb_n = n_cur;
+                    nper++; pk = 0u; stable = (eqd || occ) && fits;
+                }
+            }
+        }
+        {
+            const bool at_b = phase == 1u && pk == 0u && nper != 0u;
+            if (__any(at_b)) {
+                const bool room = in.per_hi >= i + 1u + 2u * pp;      // the dual period and at least one more to skip
+                if (!__any(at_b && !stable && room && nper < (pp > 2u ? WALK_PROBE_PERIODS : 3u))) {
+                    const bool go = at_b && stable && room;
+                    if (__any(go)) image_dirs<K>(st, cur, go, n_cur);
+                    if (go) { phase = 2u; TBacc = tb_init(); pk = 0u; }
+                    else if (at_b) {
+                        phase = 0u;
+                        if (!room) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;
+                        else {                                        // never settled: maybe the list repeats with a multiple of the period
+                            fails++; mult = mult % 8u + 1u;
+                            if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }
+                            probe_at = i + 1u + (fails ? 0u : backoff);
+                        }
+                    }
+                }
+            }
+        }
+        if (active) {
+            const bool done = accept || final_pass || !any_next;      // mfa.cpp:224-225, 227-235
+            i++;
+            if (stats) stats->steps++;
+            if (done) {
+                b.results[sid] = (warm == 0x9e3779b9u && len == 0xffffffffu) ? 3 : (accept ? 1 : 0);      // (warm keeps the touches alive)
+                active = false; phase = 0u; n_cur = 0u;
+            }
+        }
+    }
+}
+
+}  // namespace mfa_walk
+
+#endif  // MFA_WALK_CORE_H

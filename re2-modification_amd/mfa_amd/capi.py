@@ -11,12 +11,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmfa_hip.so")
 
 OK = 0
-KERNEL_NONE, KERNEL_GENERIC, KERNEL_SPECIALISED, KERNEL_TABLE = 0, 1, 2, 3
+KERNEL_NONE, KERNEL_GENERIC, KERNEL_SPECIALISED, KERNEL_TABLE, KERNEL_WALK = 0, 1, 2, 3, 4
 ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_TOO_LONG, ERR_JIT = -1, -2, -3, -4, -5, -6, -7, -8
 
 EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_image_specialize", "mfa_match_batch",
            "mfa_match_batch_regions", "mfa_region_scan", "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_last_region_ms",
-           "mfa_device_count", "mfa_last_hip_error", "mfa_strerror", "mfa_version"]
+           "mfa_device_count", "mfa_last_hip_error", "mfa_strerror", "mfa_version",
+           "mfa_mixed_create", "mfa_mixed_destroy", "mfa_match_mixed", "mfa_mixed_last_ms"]
 
 REGION_WORDS, REGION_MAX, REGION_OVERFLOW, REGION_MIN_LEN = 16, 15, 0x100, 64
 
@@ -66,6 +67,11 @@ def lib():
         L.mfa_last_region_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
         L.mfa_match_batch_host.argtypes = [vp, vp, vp, u64, vp, i32]
         L.mfa_last_kernel_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
+        L.mfa_mixed_create.argtypes = [ctypes.POINTER(vp), ctypes.c_uint32, ctypes.POINTER(vp)]
+        L.mfa_mixed_destroy.argtypes = [vp]
+        L.mfa_mixed_destroy.restype = None
+        L.mfa_match_mixed.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32, vp]
+        L.mfa_mixed_last_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.mfa_strerror.argtypes = [i32]
         L.mfa_strerror.restype = ctypes.c_char_p
         L.mfa_version.restype = ctypes.c_char_p
@@ -156,6 +162,46 @@ class Image:
     def close(self):
         if self._h:
             lib().mfa_image_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Mixed:
+    """A mixed-batch handle (mfa_mixed_t*): several memory automata matched against the segments of ONE batch."""
+
+    def __init__(self, images):
+        self._images = list(images)                      # the images must outlive the handle
+        self._h = ctypes.c_void_p()
+        arr = (ctypes.c_void_p * len(self._images))(*[im._h for im in self._images])
+        _check(lib().mfa_mixed_create(arr, len(self._images), ctypes.byref(self._h)), "mfa_mixed_create")
+
+    def match_tensors(self, d_bytes, d_offsets, seg_first, d_results=None, stream=None):
+        """seg_first: host sequence of len(images) + 1 string indices.  Asynchronous on `stream` (default: the current one)."""
+        import torch
+        n = d_offsets.numel() - 1
+        dev = d_offsets.device.index or 0
+        if d_results is None:
+            d_results = torch.empty(max(n, 1), dtype=torch.uint8, device=d_offsets.device)
+        s = stream if stream is not None else torch.cuda.current_stream(d_offsets.device)
+        sf = (ctypes.c_uint64 * len(seg_first))(*[int(x) for x in seg_first])
+        _check(lib().mfa_match_mixed(self._h, d_bytes.data_ptr(), d_offsets.data_ptr(), n, sf, d_results.data_ptr(), dev,
+                                     ctypes.c_void_p(s.cuda_stream)), "mfa_match_mixed")
+        return d_results[:n]
+
+    def last_ms(self, device=0):
+        """(region launches, first region launch to last walk) of the last call, in ms"""
+        r, sp = ctypes.c_float(), ctypes.c_float()
+        _check(lib().mfa_mixed_last_ms(self._h, device, ctypes.byref(r), ctypes.byref(sp)), "mfa_mixed_last_ms")
+        return r.value, sp.value
+
+    def close(self):
+        if self._h:
+            lib().mfa_mixed_destroy(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):
