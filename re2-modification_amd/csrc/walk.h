@@ -37,6 +37,8 @@ struct WalkLaunch {
 #define MFA_WALK_DECL(K) int launch_walk_k##K(const WalkLaunch& L, void* stream); size_t walk_wave_words_k##K(uint32_t C);
 MFA_WALK_DECL(1) MFA_WALK_DECL(2) MFA_WALK_DECL(3) MFA_WALK_DECL(4) MFA_WALK_DECL(5) MFA_WALK_DECL(6) MFA_WALK_DECL(7) MFA_WALK_DECL(8) MFA_WALK_DECL(9)
 #undef MFA_WALK_DECL
+int launch_walk_stats(const WalkLaunch& L, void* stream);      // K = 1 with counters (MFA_WALK_STATS=1; development)
+void walk_print_stats(unsigned long long* d_counter, const char* tag);
 
 }  // namespace mfa
 

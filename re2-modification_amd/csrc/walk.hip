@@ -11,6 +11,9 @@
 #include "walk.h"
 #include "walk_core.h"
 
+#ifndef WALK_STATS
+#define WALK_STATS 0
+#endif
 #ifndef WALK_K
 #error "compile with -DWALK_K=<cells>"
 #endif
@@ -41,33 +44,49 @@ struct TicketFeeder {
 };
 
 // LDS of a workgroup: [tables] then per wave [lv][ld][sb][sa][rt_cache]
-template <int K, bool REV>
+template <int K, bool REV, bool STATS>
 __global__ void __launch_bounds__(256, WALK_MIN_WAVES)
 walk_kernel(WalkArgs a) {
     extern __shared__ uint32_t smem[];
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t* const T = smem;
-    for (uint32_t k = threadIdx.x; k < a.table_words; k += blockDim.x) T[k] = a.tables[k];
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint32_t k = threadIdx.x; k < a.table_words; k += blockDim.x) smem[k] = a.tables[k];
+    const TablePtr T = (TablePtr)smem;
     __syncthreads();
     constexpr uint32_t W = Lay<K>::W, DW = Lay<K>::DW;
     const uint32_t per_wave = a.C * 64u * (3u * W + 3u * DW) + 2u * 64u * MFA_RT_CACHED;
-    uint32_t* base = smem + a.shared_words + wave * per_wave;
+    // the wave's number as a scalar: everything derived from it stays in scalar registers
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
+    WALK_LDS uint32_t* base = (WALK_LDS uint32_t*)smem + a.shared_words + wave_u * per_wave;
     Store st;
     st.C = a.C; st.CX = a.CX;
-    st.lv = base + lane; base += 2u * a.C * W * 64u;
-    st.ld = base + lane; base += 2u * a.C * DW * 64u;
-    st.sb = base + lane; base += a.C * W * 64u;
-    st.sa = base + lane; base += a.C * DW * 64u;
-    uint64_t* const rtc = reinterpret_cast<uint64_t*>(base) + lane;
-    const uint64_t gwave = (uint64_t)blockIdx.x * 4u + wave;
+    st.lv = base; base += 2u * a.C * W * 64u;
+    st.ld = base; base += 2u * a.C * DW * 64u;
+    st.sb = base; base += a.C * W * 64u;
+    st.sa = base; base += a.C * DW * 64u;
+    WALK_LDS uint64_t* const rtc = (WALK_LDS uint64_t*)base;
+    const uint64_t gwave = (uint64_t)blockIdx.x * 4u + wave_u;
     uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * (3u * W + 3u * DW));
-    st.gv = g + lane; g += 2u * a.CX * W * 64u;
-    st.gd = g + lane; g += 2u * a.CX * DW * 64u;
-    st.gsb = g + lane; g += a.CX * W * 64u;
-    st.gsa = g + lane;
+    st.gv = g; g += 2u * a.CX * W * 64u;
+    st.gd = g; g += 2u * a.CX * DW * 64u;
+    st.gsb = g; g += a.CX * W * 64u;
+    st.gsa = g;
     Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.n_seg, a.seg_first, a.seg_table};
     TicketFeeder feed{a.counter, a.n, gwave * 64u};
+#if WALK_STATS
+    // development build: per-lane counts and per-wave cycle counts, added up in a.counter[8 ..]
+    WaveStats ws;
+    walk_wave<K, REV, TicketFeeder>(b, T, st, rtc, feed, &ws);
+    unsigned long long* out = a.counter + 8;
+    const unsigned long long lanev[7] = {ws.dual * 0ull + ws.skipped, ws.probes, ws.hits, ws.steps, ws.spills, ws.strings, 0ull};
+    for (int k = 0; k < 6; k++) atomicAdd(&out[k], lanev[k]);
+    if ((threadIdx.x & 63u) == 0) {
+        const unsigned long long wavev[9] = {ws.iters, ws.dual, ws.t_start, ws.t_byte, ws.t_look, ws.t_plain, ws.t_dual, ws.t_post, ws.t_total};
+        for (int k = 0; k < 9; k++) atomicAdd(&out[8 + k], wavev[k]);
+        atomicAdd(&out[17], 1ull);
+    }
+#else
     walk_wave<K, REV, TicketFeeder>(b, T, st, rtc, feed, nullptr);
+#endif
 }
 
 #define WALK_CAT2(a, b) a##b
@@ -76,24 +95,30 @@ walk_kernel(WalkArgs a) {
 // words of LDS one wave needs at capacity C
 static size_t wave_words(uint32_t C) { return (size_t)C * 64u * (3u * Lay<WALK_K>::W + 3u * Lay<WALK_K>::DW) + 2u * 64u * MFA_RT_CACHED; }
 
+#if WALK_STATS
+int launch_walk_stats(const WalkLaunch& L, void* stream) {
+#else
 int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
+#endif
     WalkArgs a = L.args;
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = ((size_t)a.shared_words + 4u * wave_words(a.C)) * 4u;
     if (lds > 160u * 1024u) return MFA_ERR_UNSUPPORTED;
     hipError_t e;
     if (L.reversed) {
-        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, true>), dim3(L.grid), dim3(256), lds, s, a);
+        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, true, WALK_STATS != 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, true, WALK_STATS != 0>), dim3(L.grid), dim3(256), lds, s, a);
     } else {
-        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, false>), dim3(L.grid), dim3(256), lds, s, a);
+        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, false, WALK_STATS != 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, false, WALK_STATS != 0>), dim3(L.grid), dim3(256), lds, s, a);
     }
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
     return MFA_OK;
 }
 
+#if !WALK_STATS
 size_t WALK_CAT(walk_wave_words_k, WALK_K)(uint32_t C) { return wave_words(C); }
+#endif
 
 }  // namespace mfa

@@ -40,6 +40,9 @@
 #ifndef WALK_DEV
 #define WALK_DEV __device__ __forceinline__
 #endif
+#ifndef WALK_WITH_DUAL
+#define WALK_WITH_DUAL 1
+#endif
 #ifndef WALK_PROBE_PERIODS
 #define WALK_PROBE_PERIODS 5u
 #endif
@@ -51,6 +54,7 @@ namespace mfa_walk {
 #define VI_EPS   2u
 #define VI_CACC  4u
 #define VI_QUAL  8u
+#define VI_HASC  (1u << 17)
 
 #define TIE_CARRY 0u
 #define TIE_HERE  1u
@@ -58,8 +62,9 @@ namespace mfa_walk {
 
 // ---- wave primitives (one lane on the host) ---------------------------------------------------------------------------------
 #ifdef MFA_HOST_EMUL
+static unsigned long long g_ev[8];      // development counts: entries, edge evaluations, inserts, search iterations, -, -, waiting insertions
+#define WALK_EV(k) (g_ev[k]++)
 WALK_DEV uint32_t wv_lane() { return 0u; }
-WALK_DEV uint32_t wv_max(uint32_t v) { return v; }
 WALK_DEV uint64_t wv_shfl64(uint64_t v, int) { return v; }
 // the wave-wide scans of device_common.h assume 64 lanes: scalar restatements for the one-lane wave
 template <bool REV>
@@ -77,23 +82,244 @@ inline bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, uin
     return true;
 }
 #else
+#define WALK_EV(k) ((void)0)
 WALK_DEV uint32_t wv_lane() { return threadIdx.x & 63u; }
-WALK_DEV uint32_t wv_max(uint32_t v) {          // wave-wide maximum of a small count, as a scalar
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(v, o); v = t > v ? t : v; }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
-}
 WALK_DEV uint64_t wv_shfl64(uint64_t v, int L) { return ((uint64_t)__shfl((uint32_t)(v >> 32), L) << 32) | __shfl((uint32_t)v, L); }
 template <bool REV>
 WALK_DEV uint32_t coop_run_end_x(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t lane) { return coop_run_end<REV>(bytes, base, len, i0, lane); }
 WALK_DEV bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, uint32_t l, uint32_t lane) { return coop_mem_equal(bytes, pa, pb, l, lane); }
 #endif
 
+// ---- address spaces ------------------------------------------------------------------------------------------------------------
+// Pointers into LDS carry their address space in the type: through plain pointers the compiler emits FLAT instructions (which
+// count in both wait counters and return out of order) for every list access.
+#ifdef MFA_HOST_EMUL
+#define WALK_LDS
+#else
+#define WALK_LDS __attribute__((address_space(3)))
+#endif
+typedef const WALK_LDS uint32_t* TablePtr;
+
+// ---- a lane's input: its string, the byte window, what it knows about runs and periodic regions ----------------------------------
+// (device_common.h's Input, without per-lane pointers: what is the same for every lane of the wave stays in scalar registers)
+struct WIn {
+    const uint8_t*  bytes;       // wave-uniform: the whole batch
+    uint64_t        total16;     //   its size rounded up to 16: loads stay below this offset
+    const uint64_t* regions;     //   region table of the launch (regions.hip), nullptr = none
+    WALK_LDS uint64_t* rtc;      //   the wave's LDS copy of every lane's first MFA_RT_CACHED table entries, [entry][lane]
+    uint64_t base;               // offset of this lane's string
+    uint32_t len, sid;
+    uint64_t blk;                // offset of the 16 bytes in w0..w3 (any alignment), MFA_NO_WINDOW = none
+    uint32_t w0, w1, w2, w3;
+    uint64_t pblk;               // the window the lane expects to need next
+    uint32_t p0, p1, p2, p3;
+    uint32_t run_lo, run_hi, run_ch;       // scan[run_lo, run_hi) == run_ch, maximal to the right
+    uint32_t per_lo, per_hi, per_q;        // scan[j] == scan[j + per_q] for per_lo <= j < per_hi - per_q (0: none)
+    uint32_t prev_lo, prev_hi, prev_q;     // the region known before that one
+    uint32_t dual_p;                       // steps per period of the dual step in flight, 0 in plain steps
+    uint32_t rt_cnt;                       // entries of this string's table row
+};
+
+WALK_DEV void w_drop_window(WIn& in) { in.blk = MFA_NO_WINDOW; in.pblk = MFA_NO_WINDOW; }
+WALK_DEV void w_reset(WIn& in, uint64_t base, uint32_t len, uint32_t sid) {
+    in.base = base; in.len = len; in.sid = sid;
+    w_drop_window(in);
+    in.run_lo = in.run_hi = 0; in.run_ch = 0x100u;
+    in.per_lo = in.per_hi = 0; in.per_q = 0; in.dual_p = 0;
+    in.prev_lo = in.prev_hi = 0; in.prev_q = 0;
+    in.rt_cnt = 0;
+}
+
+// The table row of the lane's string: header and first MFA_RT_CACHED entries arrive in (a, b) (two 16-byte loads that go out
+// with the loads of the string's offsets); they are kept in LDS, and the input around both ends of those regions and at the end
+// of the string is touched: that is where the lane needs bytes next (a jump ends near the end of its region).
+WALK_DEV void w_rt_attach(WIn& in, uint32_t& warm, const uint4 a, const uint4 b) {
+    if (in.regions == nullptr) return;
+    const uint32_t lane = wv_lane();
+    in.rt_cnt = a.x & 0xffu;
+    const uint64_t e0 = ((uint64_t)a.w << 32) | a.z, e1 = ((uint64_t)b.y << 32) | b.x;
+    in.rtc[lane] = e0; in.rtc[WALK_WV + lane] = e1;
+    const uint64_t lim = in.total16 - 4u;
+    auto touch = [&](uint64_t off) {
+        off = off < lim ? off : lim;
+        warm ^= *reinterpret_cast<const uint32_t*>(in.bytes + (off & ~(uint64_t)3));
+    };
+    if (in.len > 64u) touch(in.base + in.len - 4u);
+    const uint64_t es[MFA_RT_CACHED] = {e0, e1};
+#pragma unroll
+    for (uint32_t k = 0; k < MFA_RT_CACHED; k++)
+        if (k < in.rt_cnt) {
+            const uint32_t mlo = (uint32_t)es[k] & 0x00ffffffu, mhi = (uint32_t)(es[k] >> 24) & 0x00ffffffu;
+            touch(in.base + mhi); touch(in.base + (mhi >= 32u ? mhi - 32u : 0u));
+            touch(in.base + mlo); touch(in.base + mlo + 32u);
+        }
+}
+// entry e in scan coordinates
+template <bool REV>
+WALK_DEV void w_rt_entry(const WIn& in, uint32_t e, uint32_t& lo, uint32_t& hi, uint32_t& q) {
+    const uint64_t w = e < MFA_RT_CACHED ? in.rtc[e * WALK_WV + wv_lane()] : in.regions[(uint64_t)in.sid * MFA_RT_WORDS + 1u + e];
+    const uint32_t mlo = (uint32_t)w & 0x00ffffffu, mhi = (uint32_t)(w >> 24) & 0x00ffffffu;
+    q = (uint32_t)(w >> 48) & 15u;
+    lo = REV ? in.len - mhi : mlo;
+    hi = REV ? in.len - mlo : mhi;
+}
+// the region with the smallest period that contains scan index i and leaves room for a probe; next = the nearest region start behind i
+template <bool REV>
+WALK_DEV bool w_rt_find(const WIn& in, uint32_t i, uint32_t mult, uint32_t& lo, uint32_t& hi, uint32_t& q, uint32_t& next) {
+    bool found = false;
+    next = ~0u; lo = hi = q = 0u;
+    for (uint32_t e = 0; e < in.rt_cnt; e++) {
+        uint32_t l, h, qq;
+        w_rt_entry<REV>(in, e, l, h, qq);
+        if (l <= i && i < h) {
+            const uint32_t m = qq * mult > 16u ? 1u : mult;
+            if (h - i >= 4u * qq * m + 24u && (!found || qq < q)) { found = true; lo = l; hi = h; q = qq; }
+        } else if (l > i && l < next) next = l;
+    }
+    return found;
+}
+// exclusive end of the run of equal bytes that contains scan index i, if the table has it (q = 1 entries are maximal runs)
+template <bool REV>
+WALK_DEV bool w_rt_run(const WIn& in, uint32_t i, uint32_t& hi) {
+    for (uint32_t e = 0; e < in.rt_cnt; e++) {
+        uint32_t l, h, qq;
+        w_rt_entry<REV>(in, e, l, h, qq);
+        if (qq == 1u && l <= i && i < h) { hi = h; return true; }
+    }
+    return false;
+}
+template <bool REV> WALK_DEV uint64_t w_scan_addr(const WIn& in, uint32_t j) { return in.base + (REV ? (uint64_t)(in.len - 1u - j) : (uint64_t)j); }
+// address of the 16-byte window whose FIRST byte in scan order is scan index j; kept inside [0, total16)
+template <bool REV> WALK_DEV uint64_t w_window_addr(const WIn& in, uint32_t j) {
+    if (REV) { const uint64_t e = in.base + in.len; return e >= (uint64_t)j + 16u ? e - j - 16u : 0; }
+    const uint64_t a = in.base + j;
+    return a + 16u <= in.total16 ? a : in.total16 - 16u;
+}
+// every 16th iteration, all lanes: take the window asked for at the last turn, ask for the one after it (device_common.h, "the byte window")
+template <bool REV> WALK_DEV void w_window_turn(WIn& in, uint32_t i, bool reading) {
+    if (reading && w_scan_addr<REV>(in, i) - in.pblk < 16u) { in.w0 = in.p0; in.w1 = in.p1; in.w2 = in.p2; in.w3 = in.p3; in.blk = in.pblk; }
+    in.pblk = MFA_NO_WINDOW;
+    if (reading && i + 16u < in.len) {
+        const uint64_t b = w_window_addr<REV>(in, i + 16u);
+        const uint4 d = load16u(in.bytes, b);
+        in.p0 = d.x; in.p1 = d.y; in.p2 = d.z; in.p3 = d.w; in.pblk = b;
+    }
+}
+// the byte at scan index i (i < len); to_turn = iterations until the next window turn, this one included (1..16)
+template <bool REV> WALK_DEV uint32_t w_stream_byte(WIn& in, uint32_t i, uint32_t to_turn) {
+    const uint64_t addr = w_scan_addr<REV>(in, i);
+    uint64_t o = addr - in.blk;
+    if (o >= 16u) {                                      // a string begins, or a jump has landed here
+        const uint64_t a = w_window_addr<REV>(in, i);
+        const uint4 d = load16u(in.bytes, a);
+        in.pblk = MFA_NO_WINDOW;
+        if (i + to_turn < in.len) {                      // where the lane will be at the next turn if it walks on step by step
+            const uint64_t b = w_window_addr<REV>(in, i + to_turn);
+            const uint4 e = load16u(in.bytes, b);
+            in.p0 = e.x; in.p1 = e.y; in.p2 = e.z; in.p3 = e.w; in.pblk = b;
+        }
+        in.w0 = d.x; in.w1 = d.y; in.w2 = d.z; in.w3 = d.w; in.blk = a;
+        o = addr - a;
+    }
+    const uint32_t ob = (uint32_t)o;
+    const uint32_t lo = (ob & 4u) ? in.w1 : in.w0;
+    const uint32_t hi = (ob & 4u) ? in.w3 : in.w2;
+    const uint32_t w = (ob & 8u) ? hi : lo;
+    return (w >> ((ob & 3u) * 8u)) & 0xffu;
+}
+// exclusive end of the run of byte c that starts at scan index i, looking at no more than `limit` positions (false: it goes on)
+template <bool REV> WALK_DEV bool w_run_end_bounded(const WIn& in, uint32_t i, uint32_t c, uint32_t limit, uint32_t& end) {
+    if (i + 1u >= in.len) { end = in.len; return true; }
+    if (!REV) {
+        const uint64_t p = in.base + i + 1u, e = in.base + in.len, e2 = e - p > limit ? p + limit : e;
+        const uint64_t q = first_not_equal(in.bytes, p, e2, c);
+        if (q < e2 || e2 == e) { end = (uint32_t)(q - in.base); return true; }
+        return false;
+    }
+    const int64_t lo = (int64_t)in.base, hi = (int64_t)(in.base + in.len - 2u - i), lo2 = hi - lo >= (int64_t)limit ? hi - (int64_t)limit + 1 : lo;
+    const int64_t q = last_not_equal(in.bytes, lo2, hi, c);
+    if (q >= lo2) { end = (uint32_t)((int64_t)in.len - 1 - (q - lo)); return true; }
+    if (lo2 == lo) { end = in.len; return true; }
+    return false;
+}
+// equality of scan[a, a+l) and scan[b, b+l), lane by lane (short spans only)
+template <bool REV> WALK_DEV bool w_spans_equal(const WIn& in, uint32_t a, uint32_t b, uint32_t l) {
+    const uint8_t* pa = in.bytes + (REV ? in.base + (in.len - a - l) : in.base + a);
+    const uint8_t* pb = in.bytes + (REV ? in.base + (in.len - b - l) : in.base + b);
+    uint32_t k = 0;
+    for (; k + 8 <= l; k += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, pa + k, 8);
+        __builtin_memcpy(&y, pb + k, 8);
+        if (x != y) return false;
+    }
+    for (; k < l; k++)
+        if (pa[k] != pb[k]) return false;
+    return true;
+}
+// end of the run of equal bytes that contains i as a value of type U: in a dual step over a region with period > 1 the run structure
+// repeats every period, the end moves with i
+WALK_DEV uint32_t w_run_hi_u(const WIn& in, uint32_t, tb_t&) { return in.run_hi; }
+WALK_DEV Dual w_run_hi_u(const WIn& in, Dual, tb_t& TB) {
+    if (in.per_q <= 1u || in.dual_p == 0u) return Dual{in.run_hi, 0};
+    Dual r{in.run_hi, (int32_t)in.dual_p};
+    (void)lt(r, Dual{in.per_hi, 0}, TB);                 // exact only while the shifted run ends inside the periodic region
+    return r;
+}
+// byte-wise comparison of a cell value with the text at i: is its outcome the same in every period?
+WALK_DEV void w_spans_period_bound(const WIn&, uint32_t, uint32_t, uint32_t, tb_t&) {}
+WALK_DEV void w_spans_period_bound(const WIn& in, Dual i, Dual start, Dual l, tb_t& TB) {
+    const bool ok = in.dual_p != 0u && in.per_q != 0u && l.d == 0 && start.d >= 0 && (uint32_t)start.d % in.per_q == 0u &&
+                    start.v >= in.per_lo && i.v >= in.per_lo;
+    if (!ok) { tb_min(TB, 1); return; }
+    (void)le(add(i, l), Dual{in.per_hi, 0}, TB);         // both sides stay inside the periodic region: the same bytes every period
+    if (start.d != 0) (void)le(add(start, l), Dual{in.per_hi, 0}, TB);
+}
+WALK_DEV bool w_span_in_region(const WIn& in, uint32_t s, uint32_t l, uint32_t& q) {
+    if (in.per_q != 0u && s >= in.per_lo && s + l <= in.per_hi) { q = in.per_q; return true; }
+    if (in.prev_q != 0u && s >= in.prev_lo && s + l <= in.prev_hi) { q = in.prev_q; return true; }
+    return false;
+}
+// would the cell read have to look for the end of the run of bytes at i?  (then the whole wave finds it first)
+WALK_DEV bool w_uni_needs_run(const WIn& in, uint32_t i, uint32_t ch, uint32_t l, uint32_t fl) {
+    if (!(fl & F_UNI) || l <= 1u || in.len - i < l) return false;
+    const uint32_t c = (fl >> 8) & 0xffu;
+    return c == ch && !(in.run_ch == c && in.run_lo <= i && i < in.run_hi);
+}
+// A cell read without its byte-wise comparison: the outcome, or need_cmp when scan[i, i+l) has to be compared with
+// scan[start, start+l) byte by byte (the caller does that with the whole wave).  mfa.cpp:178-187
+template <bool REV, class U>
+WALK_DEV bool w_read_pre(WIn& in, U i, uint32_t ch, U start, U l, uint32_t fl, tb_t& TB, bool& need_cmp) {
+    if (lt(sub(konst<U>(in.len), i), l, TB)) return false;
+    if (eq(l, konst<U>(0u), TB)) return true;
+    if (fl & F_UNI) {                                    // the value is one byte repeated: compare its length with the run of bytes at i
+        const uint32_t c = (fl >> 8) & 0xffu;
+        if (c != ch) return false;
+        if (eq(l, konst<U>(1u), TB)) return true;
+        // (the caller has made sure the run at i is known: w_uni_needs_run)
+        return ge(sub(w_run_hi_u(in, i, TB), i), l, TB);
+    }
+    if (((fl >> 8) & 0xffu) != ch) return false;          // bits 8..15 of the flags hold the FIRST byte of a non-empty value
+    w_spans_period_bound(in, i, start, l, TB);
+    const uint32_t lv = val(l), head = lv < 16u ? lv : 16u;
+    if (!w_spans_equal<REV>(in, REV ? val(start) + (lv - head) : val(start), REV ? val(i) + (lv - head) : val(i), head)) return false;
+    if (lv <= 16u) return true;
+    // two q-periodic spans (q <= 8) whose first 16 bytes agree are equal.  Plain steps only (a lane in its dual period has to
+    // bound the outcome over the periods to come: w_spans_period_bound above).
+    if (in.dual_p == 0u) {
+        uint32_t qa = 0, qb = 0;
+        if (w_span_in_region(in, val(start), lv, qa) && w_span_in_region(in, val(i), lv, qb) && qa == qb) return true;
+    }
+    need_cmp = true;
+    return false;
+}
+
 // ---- per-lane view of an automaton's tables ------------------------------------------------------------------------------------
 struct Aut {
     uint32_t cmap, vinfo, vc, vb, ee;      // word offsets into the table block
     uint32_t nc, vbits, start;
 };
-WALK_DEV void aut_load(Aut& a, const uint32_t* T, uint32_t at) {
+WALK_DEV void aut_load(Aut& a, TablePtr T, uint32_t at) {
     a.cmap = at + T[at + 5]; a.vinfo = at + T[at + 6]; a.vc = at + T[at + 7]; a.vb = at + T[at + 8]; a.ee = at + T[at + 9];
     a.nc = T[at + 2]; a.vbits = T[at + 1]; a.start = T[at + 4];
 }
@@ -105,11 +331,11 @@ template <int K> struct Lay {
     static constexpr uint32_t EEW = K <= 6 ? 2 : 3;      // words per effective edge
 };
 
-struct Store {               // all pointers already offset by the lane
-    uint32_t* lv;            // LDS  [2][C][W][WV]    list values
-    uint32_t* ld;            // LDS  [2][C][DW][WV]   list directions (dual steps)
-    uint32_t* sb;            // LDS  [C][W][WV]       the list one period ago
-    uint32_t* sa;            // LDS  [C][DW][WV]      the movement over the last period
+struct Store {               // wave-uniform bases; every access adds the lane
+    WALK_LDS uint32_t* lv;   // LDS  [2][C][W][WV]    list values
+    WALK_LDS uint32_t* ld;   // LDS  [2][C][DW][WV]   list directions (dual steps)
+    WALK_LDS uint32_t* sb;   // LDS  [C][W][WV]       the list one period ago
+    WALK_LDS uint32_t* sa;   // LDS  [C][DW][WV]      the movement over the last period
     uint32_t* gv;            // global [2][CX][W][WV]  entries C, C+1, ... of either list
     uint32_t* gd;            // global [2][CX][DW][WV]
     uint32_t* gsb;           // global [CX][W][WV]
@@ -117,17 +343,64 @@ struct Store {               // all pointers already offset by the lane
     uint32_t C, CX;
 };
 
+// single words (the images of a probe use them: rare)
 template <int K> WALK_DEV uint32_t rd_v(const Store& st, uint32_t l, uint32_t e, uint32_t w) {
-    return e < st.C ? st.lv[((l * st.C + e) * Lay<K>::W + w) * WALK_WV] : st.gv[((l * st.CX + (e - st.C)) * Lay<K>::W + w) * WALK_WV];
+    return e < st.C ? st.lv[((l * st.C + e) * Lay<K>::W + w) * WALK_WV + wv_lane()] : st.gv[((l * st.CX + (e - st.C)) * Lay<K>::W + w) * WALK_WV + wv_lane()];
 }
 template <int K> WALK_DEV void wr_v(const Store& st, uint32_t l, uint32_t e, uint32_t w, uint32_t v) {
-    if (e < st.C) st.lv[((l * st.C + e) * Lay<K>::W + w) * WALK_WV] = v; else st.gv[((l * st.CX + (e - st.C)) * Lay<K>::W + w) * WALK_WV] = v;
+    if (e < st.C) st.lv[((l * st.C + e) * Lay<K>::W + w) * WALK_WV + wv_lane()] = v; else st.gv[((l * st.CX + (e - st.C)) * Lay<K>::W + w) * WALK_WV + wv_lane()] = v;
 }
 template <int K> WALK_DEV uint32_t rd_d(const Store& st, uint32_t l, uint32_t e, uint32_t w) {
-    return e < st.C ? st.ld[((l * st.C + e) * Lay<K>::DW + w) * WALK_WV] : st.gd[((l * st.CX + (e - st.C)) * Lay<K>::DW + w) * WALK_WV];
+    return e < st.C ? st.ld[((l * st.C + e) * Lay<K>::DW + w) * WALK_WV + wv_lane()] : st.gd[((l * st.CX + (e - st.C)) * Lay<K>::DW + w) * WALK_WV + wv_lane()];
 }
 template <int K> WALK_DEV void wr_d(const Store& st, uint32_t l, uint32_t e, uint32_t w, uint32_t v) {
-    if (e < st.C) st.ld[((l * st.C + e) * Lay<K>::DW + w) * WALK_WV] = v; else st.gd[((l * st.CX + (e - st.C)) * Lay<K>::DW + w) * WALK_WV] = v;
+    if (e < st.C) st.ld[((l * st.C + e) * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v; else st.gd[((l * st.CX + (e - st.C)) * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v;
+}
+
+// whole entries: ONE branch on where the entry lives, then W (or DW) accesses with constant offsets from one address
+template <int K> WALK_DEV void rd_words(const Store& st, uint32_t l, uint32_t e, uint32_t (&w)[Lay<K>::W]) {
+    if (e < st.C) {
+        const WALK_LDS uint32_t* p = st.lv + ((l * st.C + e) * Lay<K>::W) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::W; k++) w[k] = p[k * WALK_WV];
+    } else {
+        const uint32_t* p = st.gv + (size_t)((l * st.CX + (e - st.C)) * Lay<K>::W) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::W; k++) w[k] = p[k * WALK_WV];
+    }
+}
+template <int K> WALK_DEV void wr_words(const Store& st, uint32_t l, uint32_t e, const uint32_t (&w)[Lay<K>::W]) {
+    if (e < st.C) {
+        WALK_LDS uint32_t* p = st.lv + ((l * st.C + e) * Lay<K>::W) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::W; k++) p[k * WALK_WV] = w[k];
+    } else {
+        uint32_t* p = st.gv + (size_t)((l * st.CX + (e - st.C)) * Lay<K>::W) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::W; k++) p[k * WALK_WV] = w[k];
+    }
+}
+template <int K> WALK_DEV void rd_dwords(const Store& st, uint32_t l, uint32_t e, uint32_t (&w)[Lay<K>::DW]) {
+    if (e < st.C) {
+        const WALK_LDS uint32_t* p = st.ld + ((l * st.C + e) * Lay<K>::DW) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::DW; k++) w[k] = p[k * WALK_WV];
+    } else {
+        const uint32_t* p = st.gd + (size_t)((l * st.CX + (e - st.C)) * Lay<K>::DW) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::DW; k++) w[k] = p[k * WALK_WV];
+    }
+}
+template <int K> WALK_DEV void wr_dwords(const Store& st, uint32_t l, uint32_t e, const uint32_t (&w)[Lay<K>::DW]) {
+    if (e < st.C) {
+        WALK_LDS uint32_t* p = st.ld + ((l * st.C + e) * Lay<K>::DW) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::DW; k++) p[k * WALK_WV] = w[k];
+    } else {
+        uint32_t* p = st.gd + (size_t)((l * st.CX + (e - st.C)) * Lay<K>::DW) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::DW; k++) p[k * WALK_WV] = w[k];
+    }
 }
 
 // an entry in registers
@@ -141,7 +414,8 @@ template <int K> WALK_DEV void load_dirs(const Store&, uint32_t, uint32_t, bool,
 template <int K> WALK_DEV void load_dirs(const Store& st, uint32_t l, uint32_t e, bool want, Ent<Dual, K>& x) {
     uint32_t w[Lay<K>::DW];
 #pragma unroll
-    for (uint32_t k = 0; k < Lay<K>::DW; k++) w[k] = want ? rd_d<K>(st, l, e, k) : 0u;
+    for (uint32_t k = 0; k < Lay<K>::DW; k++) w[k] = 0u;
+    if (want) rd_dwords<K>(st, l, e, w);
     x.P.d = d16(w[0], 0) * 16;
 #pragma unroll
     for (int c = 0; c < K; c++) { x.S[c].d = d16(w[(1 + 2 * c) / 2], 1 + 2 * c); x.L[c].d = d16(w[(2 + 2 * c) / 2], 2 + 2 * c); }
@@ -153,8 +427,7 @@ template <int K> WALK_DEV void load_pdir(const Store& st, uint32_t l, uint32_t e
 // want_d: the lane's directions are meaningful (it is in its dual period); other lanes carry direction 0
 template <class U, int K> WALK_DEV void load_entry(const Store& st, uint32_t l, uint32_t e, bool want_d, Ent<U, K>& x) {
     uint32_t w[Lay<K>::W];
-#pragma unroll
-    for (uint32_t k = 0; k < Lay<K>::W; k++) w[k] = rd_v<K>(st, l, e, k);
+    rd_words<K>(st, l, e, w);
     setv(x.P, w[0]);
     x.vid = w[1] & 0xffffu;
 #pragma unroll
@@ -178,18 +451,22 @@ template <int K> WALK_DEV void store_dirs(const Store& st, uint32_t l, uint32_t 
 #pragma unroll
     for (uint32_t k = 0; k < 2 * Lay<K>::DW; k++) ok = ok && d[k] == (int32_t)(int16_t)d[k];
     if (!ok) fits = false;
+    uint32_t w[Lay<K>::DW];
 #pragma unroll
-    for (uint32_t k = 0; k < Lay<K>::DW; k++) wr_d<K>(st, l, e, k, ((uint32_t)d[2 * k] & 0xffffu) | ((uint32_t)d[2 * k + 1] << 16));
+    for (uint32_t k = 0; k < Lay<K>::DW; k++) w[k] = ((uint32_t)d[2 * k] & 0xffffu) | ((uint32_t)d[2 * k + 1] << 16);
+    wr_dwords<K>(st, l, e, w);
 }
 
 template <class U, int K> WALK_DEV void store_entry(const Store& st, uint32_t l, uint32_t e, const Ent<U, K>& x, uint32_t tie, bool& fits) {
-    wr_v<K>(st, l, e, 0, val(x.P));
-    wr_v<K>(st, l, e, 1, x.vid | (tie << 16));
+    uint32_t w[Lay<K>::W];
+    w[0] = val(x.P);
+    w[1] = x.vid | (tie << 16);
 #pragma unroll
     for (int c = 0; c < K; c++) {
-        wr_v<K>(st, l, e, 2 + 2 * c, (val(x.S[c]) & 0x00ffffffu) | ((x.F[c] >> 8) << 24));
-        wr_v<K>(st, l, e, 3 + 2 * c, (val(x.L[c]) & 0x00ffffffu) | ((x.F[c] & 0xfu) << 24));
+        w[2 + 2 * c] = (val(x.S[c]) & 0x00ffffffu) | ((x.F[c] >> 8) << 24);
+        w[3 + 2 * c] = (val(x.L[c]) & 0x00ffffffu) | ((x.F[c] & 0xfu) << 24);
     }
+    wr_words<K>(st, l, e, w);
     store_dirs<K>(st, l, e, x, fits);
 }
 
@@ -226,13 +503,13 @@ WALK_DEV void apply_actions(Ent<U, K>& t, uint32_t actions, bool pred, U ts, U t
 // ---- a cell read (mfa.cpp:177-191) on the lanes in `rd`: does scan[i, i + |v|) equal the value? ----------------------------------------
 // Run extents and byte-wise comparisons are done by the whole wave, one lane's at a time (device_common.h).
 template <bool REV, class U>
-WALK_DEV bool cell_read(Input& in, bool rd, U i, uint32_t ch, U vs, U vl, uint32_t vf, tb_t& TB) {
+WALK_DEV bool cell_read(WIn& in, bool rd, U i, uint32_t ch, U vs, U vl, uint32_t vf, tb_t& TB) {
     const uint32_t lane = wv_lane();
     {
-        bool nr = rd && uni_needs_run(in, val(i), ch, val(vl), vf);
-        if (nr && in.rt != nullptr) {                    // the region pass knows every long run
+        bool nr = rd && w_uni_needs_run(in, val(i), ch, val(vl), vf);
+        if (nr && in.regions != nullptr) {                    // the region pass knows every long run
             uint32_t rh;
-            if (rt_run<REV>(in, val(i), rh) || run_end_bounded<REV>(in, val(i), ch, 192u, rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }
+            if (w_rt_run<REV>(in, val(i), rh) || w_run_end_bounded<REV>(in, val(i), ch, 192u, rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }
         }
         for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {
             const int L = __builtin_ctzll(sb);
@@ -245,7 +522,7 @@ WALK_DEV bool cell_read(Input& in, bool rd, U i, uint32_t ch, U vs, U vl, uint32
         }
     }
     bool ok = false, cmp = false;
-    if (rd) ok = read_pre_u<REV, U>(in, i, ch, vs, vl, vf, TB, cmp);
+    if (rd) ok = w_read_pre<REV, U>(in, i, ch, vs, vl, vf, TB, cmp);
     for (unsigned long long sb = __ballot(cmp); sb; sb &= sb - 1ull) {
         const int L = __builtin_ctzll(sb);
         const uint32_t ca = val(vs), cb = val(i), cl = val(vl);
@@ -257,6 +534,7 @@ WALK_DEV bool cell_read(Input& in, bool rd, U i, uint32_t ch, U vs, U vl, uint32
 }
 
 // ---- the step --------------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t KEYS = 4;      // entries of the list being built whose keys are also kept in registers
 template <class U, int K>
 struct StepCtx {
     const Store& st;
@@ -265,35 +543,45 @@ struct StepCtx {
     bool dual_lane;          // per lane: directions are meaningful
     bool fits;               // per lane: every direction stored so far fits 16 bits
     tb_t TB;
+    // the first KEYS entries' node | tie << 16 and P: a candidate for one of them is decided without reading the list
+    uint32_t k_id[KEYS], k_P[KEYS];
 };
 
 // candidate (P, tie, cells of t) for the node of `vid` on the lanes in `pred`
 template <class U, int K>
 WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits, U P, uint32_t tie, Ent<U, K>& t) {
     const uint32_t node = vid >> vbits;
-    uint32_t at = ~0u, w1 = 0;
-    const uint32_t most = wv_max(pred ? cx.n_next : 0u);
-    for (uint32_t j = 0; j < most; j++) {                        // is there an entry for this node already?
-        const bool look = pred && j < cx.n_next;
-        const uint32_t x = look ? rd_v<K>(cx.st, cx.nxt, j, 1) : 0u;
-        if (look && ((x & 0xffffu) >> vbits) == node) { at = j; w1 = x; }
+    if (pred) WALK_EV(2);
+    uint32_t at = ~0u, old_tie = 0u;
+    U old = konst<U>(0u);
+#pragma unroll
+    for (uint32_t k = 0; k < KEYS; k++)
+        if (pred && k < cx.n_next && (cx.k_id[k] & 0xffffu) == node) { at = k; old_tie = cx.k_id[k] >> 16; setv(old, cx.k_P[k]); }
+    if (__any(pred && at == ~0u && cx.n_next > KEYS)) {        // longer lists: look through the rest
+        for (uint32_t j = KEYS; __any(pred && at == ~0u && j < cx.n_next); j++) {
+            WALK_EV(3);
+            const bool look = pred && at == ~0u && j < cx.n_next;
+            const uint32_t x = look ? rd_v<K>(cx.st, cx.nxt, j, 1) : 0u;
+            if (look && ((x & 0xffffu) >> vbits) == node) { at = j; old_tie = x >> 16; setv(old, rd_v<K>(cx.st, cx.nxt, j, 0)); }
+        }
     }
     bool win = pred;
     if (pred && at != ~0u) {
-        U old;
-        setv(old, rd_v<K>(cx.st, cx.nxt, at, 0));
         load_pdir<K>(cx.st, cx.nxt, at, cx.dual_lane, old);
-        win = lt(P, old, cx.TB) || (eq(P, old, cx.TB) && tie < (w1 >> 16));
+        win = lt(P, old, cx.TB) || (eq(P, old, cx.TB) && tie < old_tie);
     }
     if (win) {
         if (at == ~0u) at = cx.n_next++;
         t.P = P; t.vid = vid;
         store_entry<U, K>(cx.st, cx.nxt, at, t, tie, cx.fits);
+#pragma unroll
+        for (uint32_t k = 0; k < KEYS; k++)
+            if (at == k) { cx.k_id[k] = node | (tie << 16); cx.k_P[k] = val(P); }
     }
 }
 
 template <int K>
-WALK_DEV void ee_decode(const uint32_t* T, uint32_t at, bool p, uint32_t& e0, uint32_t& actions, uint32_t& cm, uint32_t& com, uint32_t& rdm) {
+WALK_DEV void ee_decode(TablePtr T, uint32_t at, bool p, uint32_t& e0, uint32_t& actions, uint32_t& cm, uint32_t& com, uint32_t& rdm) {
     e0 = p ? T[at] : 0u;
     const uint32_t e1 = p ? T[at + 1] : 0u;
     if (Lay<K>::EEW == 2) {
@@ -319,15 +607,18 @@ WALK_DEV void frame_state(const Ent<U, K>& E, U pos, uint32_t cm, uint32_t com, 
 }
 
 // One MFA::evaluateStates call (mfa.cpp:203-213) for every active lane: reads list `cur` (n_cur entries), builds the other one.
+#ifndef WALK_STEP_ATTR
+#define WALK_STEP_ATTR WALK_DEV
+#endif
 template <class U, int K, bool REV>
-WALK_DEV void walk_step(const Store& st, const uint32_t* T, const Aut& au, Input& in, uint32_t cur, uint32_t n_cur, uint32_t& n_next,
+WALK_STEP_ATTR void walk_step(const Store& st, TablePtr T, const Aut& au, WIn& in, uint32_t cur, uint32_t n_cur, uint32_t& n_next,
                         const U i, const U len, const uint32_t ch, const bool final_pass, const bool active, const bool dual_lane,
                         bool& accept, bool& fits, tb_t& TB) {
-    StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB};
+    StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
     const uint32_t cls = (active && !final_pass) ? (T[au.cmap + ((ch & 0xffu) >> 2)] >> (8u * (ch & 3u))) & 0xffu : 0u;
-    const uint32_t most = wv_max(active ? n_cur : 0u);
-    for (uint32_t e = 0; e < most; e++) {
+    for (uint32_t e = 0; __any(active && e < n_cur); e++) {
         const bool have = active && e < n_cur;
+        if (have) WALK_EV(0);
         Ent<U, K> E;
         load_entry<U, K>(st, cur, have ? e : 0u, dual_lane && have, E);
         const U pos = have ? posof(E.P, cx.TB) : konst<U>(0u);
@@ -354,14 +645,15 @@ WALK_DEV void walk_step(const Store& st, const uint32_t* T, const Aut& au, Input
         // ---- the state at pos == i consumes (mfa.cpp:161-194)
         if (__any(here)) {
             const uint32_t bl = here ? T[au.vb + E.vid * au.nc + cls] : 0u;
-            const uint32_t bbeg = bl >> 12, bcnt = bl & 0xfffu, bmost = wv_max(bcnt);
-            for (uint32_t j = 0; j < bmost; j++) {
+            const uint32_t bbeg = bl >> 12, bcnt = bl & 0xfffu;
+            for (uint32_t j = 0; __any(j < bcnt); j++) {
                 const bool p = here && j < bcnt;
+                if (p) WALK_EV(1);
                 uint32_t e0, actions, cm, com, rdm;
                 ee_decode<K>(T, au.ee + (bbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
                 const uint32_t tvid = e0 >> 9, tfn = (e0 >> 5) & 15u, cell = (e0 >> 1) & 15u;
-                Ent<U, K> s;
-                frame_state<U, K>(E, pos, cm, com, rdm, s);
+                Ent<U, K> s = E;                                     // (most edges start from the entry's own cells)
+                if (__any(p && (cm | rdm) != 0u)) frame_state<U, K>(E, pos, cm, com, rdm, s);
                 const bool lit = p && (e0 & 1u) == 0u, rd = p && (e0 & 1u) != 0u;
                 if (__any(lit)) {                                    // a letter (or dot) edge takes the byte (mfa.cpp:171-175)
                     Ent<U, K> t = s;
@@ -386,11 +678,12 @@ WALK_DEV void walk_step(const Store& st, const uint32_t* T, const Aut& au, Input
         // ---- a waiting state (and, in the final pass, a state at pos == len) only follows edges of absent cells (mfa.cpp:148-160)
         const bool late = live && !here;
         if ((vi & VI_CACC) && late && !accept && eq(pos, len, cx.TB)) accept = true;
-        if (__any(wait)) {
-            const uint32_t cl = wait ? T[au.vc + E.vid] : 0u;
-            const uint32_t cbeg = cl >> 12, ccnt = cl & 0xfffu, cmost = wv_max(ccnt);
-            for (uint32_t j = 0; j < cmost; j++) {
+        if (__any(wait && (vi & VI_HASC) != 0u)) {
+            const uint32_t cl = (wait && (vi & VI_HASC) != 0u) ? T[au.vc + E.vid] : 0u;
+            const uint32_t cbeg = cl >> 12, ccnt = cl & 0xfffu;
+            for (uint32_t j = 0; __any(j < ccnt); j++) {
                 const bool p = wait && j < ccnt;
+                if (p) WALK_EV(6);
                 uint32_t e0, actions, cm, com, rdm;
                 ee_decode<K>(T, au.ee + (cbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
                 Ent<U, K> t;
@@ -403,13 +696,13 @@ WALK_DEV void walk_step(const Store& st, const uint32_t* T, const Aut& au, Input
 }
 
 // ---- the list one period ago (SB) and its movement (SA) ----------------------------------------------------------------------------------
-template <int K> WALK_DEV uint32_t sb_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.C ? st.sb[(e * Lay<K>::W + w) * WALK_WV] : st.gsb[((e - st.C) * Lay<K>::W + w) * WALK_WV]; }
+template <int K> WALK_DEV uint32_t sb_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.C ? st.sb[(e * Lay<K>::W + w) * WALK_WV + wv_lane()] : st.gsb[((e - st.C) * Lay<K>::W + w) * WALK_WV + wv_lane()]; }
 template <int K> WALK_DEV void sb_wr(const Store& st, uint32_t e, uint32_t w, uint32_t v) {
-    if (e < st.C) st.sb[(e * Lay<K>::W + w) * WALK_WV] = v; else st.gsb[((e - st.C) * Lay<K>::W + w) * WALK_WV] = v;
+    if (e < st.C) st.sb[(e * Lay<K>::W + w) * WALK_WV + wv_lane()] = v; else st.gsb[((e - st.C) * Lay<K>::W + w) * WALK_WV + wv_lane()] = v;
 }
-template <int K> WALK_DEV uint32_t sa_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.C ? st.sa[(e * Lay<K>::DW + w) * WALK_WV] : st.gsa[((e - st.C) * Lay<K>::DW + w) * WALK_WV]; }
+template <int K> WALK_DEV uint32_t sa_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.C ? st.sa[(e * Lay<K>::DW + w) * WALK_WV + wv_lane()] : st.gsa[((e - st.C) * Lay<K>::DW + w) * WALK_WV + wv_lane()]; }
 template <int K> WALK_DEV void sa_wr(const Store& st, uint32_t e, uint32_t w, uint32_t v) {
-    if (e < st.C) st.sa[(e * Lay<K>::DW + w) * WALK_WV] = v; else st.gsa[((e - st.C) * Lay<K>::DW + w) * WALK_WV] = v;
+    if (e < st.C) st.sa[(e * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v; else st.gsa[((e - st.C) * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v;
 }
 
 // index of a value word's direction: 0 = P (in units of 16), 1 + 2c = S of cell c, 2 + 2c = L of cell c; word 1 has none
@@ -417,8 +710,7 @@ WALK_DEV int dir_index(uint32_t w) { return w == 0u ? 0 : (int)w - 1; }
 
 // save list `cur` of the lanes in `pred`
 template <int K> WALK_DEV void image_save(const Store& st, uint32_t cur, bool pred, uint32_t n) {
-    const uint32_t most = wv_max(pred ? n : 0u);
-    for (uint32_t e = 0; e < most; e++)
+    for (uint32_t e = 0; __any(pred && e < n); e++)
         if (pred && e < n) {
 #pragma unroll
             for (uint32_t w = 0; w < Lay<K>::W; w++) { const uint32_t v = rd_v<K>(st, cur, e, w); sb_wr<K>(st, e, w, w == 1u ? (v & 0xffffu) : v); }
@@ -430,8 +722,7 @@ template <int K> WALK_DEV void image_save(const Store& st, uint32_t cur, bool pr
 template <int K> WALK_DEV void image_measure(const Store& st, uint32_t cur, bool pred, uint32_t n, uint32_t sb_n, bool& moved, bool& wide, bool& vac) {
     moved = wide = vac = false;
     if (pred && n != sb_n) { moved = true; vac = true; }
-    const uint32_t most = wv_max(pred ? n : 0u);
-    for (uint32_t e = 0; e < most; e++)
+    for (uint32_t e = 0; __any(pred && e < n); e++)
         if (pred && e < n) {
             int32_t d[2 * Lay<K>::DW];
 #pragma unroll
@@ -459,8 +750,7 @@ template <int K> WALK_DEV void image_measure(const Store& st, uint32_t cur, bool
 
 // the lanes in `pred` start their dual period: the list's directions are the movement just measured
 template <int K> WALK_DEV void image_dirs(const Store& st, uint32_t cur, bool pred, uint32_t n) {
-    const uint32_t most = wv_max(pred ? n : 0u);
-    for (uint32_t e = 0; e < most; e++)
+    for (uint32_t e = 0; __any(pred && e < n); e++)
         if (pred && e < n) {
 #pragma unroll
             for (uint32_t k = 0; k < Lay<K>::DW; k++) wr_d<K>(st, cur, e, k, sa_rd<K>(st, e, k));
@@ -470,8 +760,7 @@ template <int K> WALK_DEV void image_dirs(const Store& st, uint32_t cur, bool pr
 // after the dual period: did the list move by exactly SA again, and was SA mapped to itself?
 template <int K> WALK_DEV bool image_same(const Store& st, uint32_t cur, bool pred, uint32_t n, uint32_t sb_n) {
     bool same = pred && n == sb_n;
-    const uint32_t most = wv_max(same ? n : 0u);
-    for (uint32_t e = 0; e < most; e++)
+    for (uint32_t e = 0; __any(same && e < n); e++)
         if (same && e < n) {
             uint32_t differs = 0u;
             int32_t dv[2 * Lay<K>::DW];
@@ -500,8 +789,7 @@ template <int K> WALK_DEV bool image_same(const Store& st, uint32_t cur, bool pr
 
 // list += skip * direction
 template <int K> WALK_DEV void image_advance(const Store& st, uint32_t cur, bool pred, uint32_t n, uint32_t skip) {
-    const uint32_t most = wv_max(pred ? n : 0u);
-    for (uint32_t e = 0; e < most; e++)
+    for (uint32_t e = 0; __any(pred && e < n); e++)
         if (pred && e < n) {
             uint32_t dw[Lay<K>::DW];
 #pragma unroll
@@ -529,14 +817,26 @@ struct Batch {
     const uint32_t* seg_table;
 };
 
-struct WaveStats { unsigned long long iters = 0, dual = 0, skipped = 0, probes = 0, hits = 0, steps = 0, spills = 0; unsigned long long hist[80] = {0}; };
+struct WaveStats {
+    unsigned long long iters = 0, dual = 0, skipped = 0, probes = 0, hits = 0, steps = 0, spills = 0;
+    unsigned long long t_start = 0, t_byte = 0, t_look = 0, t_plain = 0, t_dual = 0, t_post = 0, t_total = 0;      // wave cycles by section (stats builds)
+    unsigned long long strings = 0;
+#ifdef MFA_HOST_EMUL
+    unsigned long long hist[80] = {0};
+#endif
+};
+#ifdef MFA_HOST_EMUL
+WALK_DEV unsigned long long wv_clock() { return 0ull; }
+#else
+WALK_DEV unsigned long long wv_clock() { return __builtin_readcyclecounter(); }
+#endif
 
 // Feeder::take(want, sid): hands the next string index to every lane that wants one; returns false when the batch is exhausted
 template <int K, bool REV, class Feeder>
-WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint64_t* rt_cache, Feeder& feed, WaveStats* stats) {
-    Input in;
-    in.bytes = b.bytes; in.total16 = (b.offsets[b.n] + 15u) & ~(uint64_t)15;
-    input_reset(in, 0, 0);
+WALK_DEV void walk_wave(const Batch& b, TablePtr T, const Store& st, WALK_LDS uint64_t* rt_cache, Feeder& feed, WaveStats* stats) {
+    WIn in;
+    in.bytes = b.bytes; in.total16 = (b.offsets[b.n] + 15u) & ~(uint64_t)15; in.regions = b.regions; in.rtc = rt_cache;
+    w_reset(in, 0, 0, 0);
     in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;
     bool active = false, exhausted = false, accept = false;
     uint32_t i = 0, len = 0; uint64_t sid = 0;
@@ -547,7 +847,10 @@ WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint
     uint32_t cur = 0, n_cur = 0, sb_n = 0, warm = 0, turn = 0;
     Aut au;
     aut_load(au, T, 0u);
+    const unsigned long long tm_begin = stats ? wv_clock() : 0ull;
     for (;;) {
+        unsigned long long tm = stats ? wv_clock() : 0ull;
+#define WALK_LAP(field) do { if (stats) { const unsigned long long now_ = wv_clock(); stats->field += now_ - tm; tm = now_; } } while (0)
         {   // hand strings to idle lanes
             const bool want = !active && !exhausted;
             if (__any(want)) {
@@ -563,8 +866,8 @@ WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint
                         if (o1 - o0 > MFA_DEV_MAX_LEN) b.results[sid] = 2;
                         else {
                             len = (uint32_t)(o1 - o0);
-                            input_reset(in, o0, len);
-                            rt_attach(in, b.regions, sid, rt_cache, WALK_WV, warm, rta, rtb);
+                            w_reset(in, o0, len, (uint32_t)sid);
+                            w_rt_attach(in, warm, rta, rtb);
                             uint32_t seg = 0;
                             for (uint32_t k = 1; k < b.n_seg; k++)
                                 if (sid >= b.seg_first[k]) seg = k;
@@ -585,19 +888,21 @@ WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint
         }
         if (!__any(active)) break;
         if (stats) stats->iters++;
+        WALK_LAP(t_start);
         const bool final_pass = (i == len);
         uint32_t ch = 0x100u;
-        if (turn == 0u) window_turn<REV>(in, i, active && !final_pass);      // the byte windows of all lanes are renewed together
-        if (active && !final_pass) ch = stream_byte<REV>(in, i, 16u - turn);
+        if (turn == 0u) w_window_turn<REV>(in, i, active && !final_pass);      // the byte windows of all lanes are renewed together
+        if (active && !final_pass) ch = w_stream_byte<REV>(in, i, 16u - turn);
         turn = (turn + 1u) & 15u;
+        WALK_LAP(t_byte);
         // ---- does this lane sit at the start of a stretch that repeats?  (probes run in epochs: all lanes that probe do it together)
         uint32_t q = 0u;
         const bool ep_busy = __any(phase != 0u);
         if (b.accel && active && !final_pass && phase == 0u && i >= probe_at && !ep_busy) {
             if (in.per_q != 0u && in.per_lo <= i && i < in.per_hi) q = in.per_q;      // still inside the region found last
-            else if (in.rt != nullptr) {
+            else if (in.regions != nullptr) {
                 uint32_t rl, rh, rq, rn;
-                if (rt_find<REV>(in, i, mult, rl, rh, rq, rn)) {
+                if (w_rt_find<REV>(in, i, mult, rl, rh, rq, rn)) {
                     if (in.per_q != 0u) { in.prev_lo = in.per_lo; in.prev_hi = in.per_hi; in.prev_q = in.per_q; }
                     in.per_lo = rl; in.per_hi = rh; in.per_q = rq; q = rq;
                 } else probe_at = rn;                                        // look again where the next region starts (never, if there is none)
@@ -619,10 +924,11 @@ WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint
             }
             if (__any(begin)) image_save<K>(st, cur, begin, n_cur);
         }
+        WALK_LAP(t_look);
         uint32_t n_next = 0;
         tb_t TB = tb_init();
         const bool p2 = phase == 2u;
-        if (__any(p2)) {
+        if (WALK_WITH_DUAL && __any(p2)) {
             // dual step: lanes in their dual period carry the list's directions, the others direction 0 (their TB is ignored)
             if (stats) stats->dual++;
             const Dual di{i, (int32_t)pp}, dlen{len, 0};
@@ -631,9 +937,11 @@ WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint
             (void)eq(di, dlen, TB);
             walk_step<Dual, K, REV>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB);
             in.dual_p = 0u;
+            WALK_LAP(t_dual);
         } else {
             bool f2 = true;
             walk_step<uint32_t, K, REV>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB);
+            WALK_LAP(t_plain);
         }
         cur ^= 1u;
         if (active) n_cur = n_next;
@@ -682,7 +990,7 @@ WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint
             }
         }
         if (__any(skip != 0u)) image_advance<K>(st, cur, skip != 0u, n_cur, skip);
-        if (skip) { i += skip * pp; input_drop_window(in); probe_at = i + 1u + pp; }
+        if (skip) { i += skip * pp; w_drop_window(in); probe_at = i + 1u + pp; }
         else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);
         if (phase == 1u) pk++;
         // plain periods of a probe: after each one the movement of the list over the period is compared with the previous period's; a
@@ -729,9 +1037,13 @@ WALK_DEV void walk_wave(const Batch& b, const uint32_t* T, const Store& st, uint
             if (done) {
                 b.results[sid] = (warm == 0x9e3779b9u && len == 0xffffffffu) ? 3 : (accept ? 1 : 0);      // (warm keeps the touches alive)
                 active = false; phase = 0u; n_cur = 0u;
+                if (stats) stats->strings++;
             }
         }
+        WALK_LAP(t_post);
     }
+#undef WALK_LAP
+    if (stats) stats->t_total += wv_clock() - tm_begin;
 }
 
 }  // namespace mfa_walk

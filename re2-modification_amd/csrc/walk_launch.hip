@@ -82,7 +82,13 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     int rc = ctx_reserve((void**)d_spill, spill_bytes, need);
     if (rc != MFA_OK) return rc;
     a.spill = *d_spill;
-    HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long), (hipStream_t)stream));
+    const bool stats = getenv("MFA_WALK_STATS") != nullptr && p.K == 1;
+    HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long) * (stats ? 32 : 1), (hipStream_t)stream));
+    if (stats) {
+        rc = launch_walk_stats(L, stream);
+        if (rc == MFA_OK) { (void)hipStreamSynchronize((hipStream_t)stream); walk_print_stats(d_counter, "walk"); }
+        return rc;
+    }
     switch (p.K) {
         case 1: return launch_walk_k1(L, stream); case 2: return launch_walk_k2(L, stream); case 3: return launch_walk_k3(L, stream);
         case 4: return launch_walk_k4(L, stream); case 5: return launch_walk_k5(L, stream); case 6: return launch_walk_k6(L, stream);
@@ -91,28 +97,52 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     return MFA_ERR_UNSUPPORTED;
 }
 
+void walk_print_stats(unsigned long long* d_counter, const char* tag) {
+    unsigned long long h[32] = {0};
+    if (hipMemcpy(h, d_counter, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+    const unsigned long long* o = h + 8;
+    const double tot = (double)o[16] > 0 ? (double)o[16] : 1.0;
+    fprintf(stderr, "%s stats: %llu waves, %llu strings, wave-iterations %llu (dual %llu), lane steps %llu, skipped %llu, probes %llu (hits %llu), spill steps %llu\n", tag,
+            o[17], o[5], o[8], o[9], o[3], o[0], o[1], o[2], o[4]);
+    fprintf(stderr, "%s stats: cycles per wave-iteration %.0f; share: string start %.1f%%, byte %.1f%%, region look-up %.1f%%, plain step %.1f%%, dual step %.1f%%, book-keeping %.1f%%\n", tag,
+            tot / (double)(o[8] ? o[8] : 1), 100.0 * o[10] / tot, 100.0 * o[11] / tot, 100.0 * o[12] / tot, 100.0 * o[13] / tot, 100.0 * o[14] / tot, 100.0 * o[15] / tot);
+}
+
 }  // namespace mfa
 
 using namespace mfa;
 
 // ---- mixed batches ---------------------------------------------------------------------------------------------------------------------
+// One batch, several automata.  The region pass runs over groups of consecutive segments on one internal stream; what walks a group
+// starts as soon as the group's regions are known and runs beside the next group's region pass:
+//   * table engine (MFA_WALK=table): ONE launch of the table-driven walk kernel per group, any lane any automaton;
+//   * generated kernels (default while they are the faster walk on small automata): one launch per segment, spread over a few walk
+//     streams by measured cost -- the first call on a device runs the walks one after the other and times them, later calls give
+//     each walk to the stream that can start it first (list scheduling with the groups' region times as release times).
+constexpr uint32_t MIX_MAX_GROUPS = 8, MIX_MAX_STREAMS = 4, MIX_MAX_LAUNCHES = 24;
+
 struct mfa_mixed {
     std::vector<mfa_image*> images;
-    std::vector<uint32_t>   words;          // the images' table blocks, back to back
+    std::vector<uint32_t>   words;          // the images' table blocks, back to back (table engine)
     std::vector<uint32_t>   block_at;       // word offset of image k's block
     uint32_t K = 1, max_live = 1;
-    bool reversed = false;
+    bool reversed = false, table_ok = true;
     std::mutex mu;
     struct Dev {
         uint32_t* d_tables = nullptr;
-        hipStream_t rs = nullptr, ws = nullptr;                // region stream, walk stream
-        std::vector<hipEvent_t> ev;                            // one per group: its regions are known
-        hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_r0 = nullptr, ev_r1 = nullptr, ev_w1 = nullptr;
+        hipStream_t rs = nullptr;                              // region stream
+        hipStream_t ws[MIX_MAX_STREAMS] = {nullptr};           // walk streams
+        hipEvent_t ev_g[MIX_MAX_GROUPS] = {nullptr};           // group g's regions are known (timed)
+        hipEvent_t ev_w[MIX_MAX_STREAMS] = {nullptr};          // end of a walk stream's work
+        hipEvent_t ev_in = nullptr, ev_r0 = nullptr, ev_end = nullptr;
         uint64_t* d_regions = nullptr; size_t region_bytes = 0;
-        uint32_t* d_spill[8] = {nullptr}; size_t spill_bytes[8] = {0};
+        uint32_t* d_spill[MIX_MAX_LAUNCHES] = {nullptr}; size_t spill_bytes[MIX_MAX_LAUNCHES] = {0};
         unsigned long long* d_counters = nullptr;
         int n_cus = 0;
-        bool timed = false;
+        bool timed = false, calibrated = false;
+        std::vector<float> cost;                               // per segment: its walk alone, ms
+        float ready[MIX_MAX_GROUPS] = {0};                     // per group: end of its region launch, ms from the start of the call
+        uint32_t ng_last = 0;
     };
     std::map<int, Dev> dev;
 };
@@ -126,21 +156,24 @@ int mfa_mixed_create(mfa_image_t* const* images, uint32_t n_images, mfa_mixed_t*
     if (!mx) return MFA_ERR_NOMEM;
     for (uint32_t k = 0; k < n_images; k++) {
         mfa_image* img = images[k];
-        if (!img || img->host.h.kind != MFA_KIND_MFA || !img->walk_ok) { delete mx; return img ? MFA_ERR_UNSUPPORTED : MFA_ERR_INVALID_ARG; }
+        if (!img) { delete mx; return MFA_ERR_INVALID_ARG; }
+        if (img->host.h.kind != MFA_KIND_MFA) { delete mx; return MFA_ERR_UNSUPPORTED; }      // memory automata (tabulated ones have no regions to share)
+        if (!img->walk_ok) mx->table_ok = false;
         if (k == 0) mx->reversed = img->walk.reversed;
-        else if (mx->reversed != img->walk.reversed) { delete mx; return MFA_ERR_UNSUPPORTED; }      // one scan direction per mixed batch
+        else if (mx->reversed != img->walk.reversed) mx->table_ok = false;                      // one scan direction per table launch
         mx->images.push_back(img);
         mx->K = std::max(mx->K, img->walk.K);
         mx->max_live = std::max(mx->max_live, img->walk.max_live);
     }
-    for (mfa_image* img : mx->images) {
-        mx->block_at.push_back((uint32_t)mx->words.size());
-        if (mx->K > 6 && img->walk.K <= 6) {                  // a kernel for more than 6 cells reads 3-word edges
-            WalkTables wide;
-            if (build_walk_tables(img->host, wide, true) != MFA_OK) { delete mx; return MFA_ERR_UNSUPPORTED; }
-            mx->words.insert(mx->words.end(), wide.words.begin(), wide.words.end());
-        } else mx->words.insert(mx->words.end(), img->walk.words.begin(), img->walk.words.end());
-    }
+    if (mx->table_ok)
+        for (mfa_image* img : mx->images) {
+            mx->block_at.push_back((uint32_t)mx->words.size());
+            if (mx->K > 6 && img->walk.K <= 6) {                  // a kernel for more than 6 cells reads 3-word edges
+                WalkTables wide;
+                if (build_walk_tables(img->host, wide, true) != MFA_OK) { mx->table_ok = false; break; }
+                mx->words.insert(mx->words.end(), wide.words.begin(), wide.words.end());
+            } else mx->words.insert(mx->words.end(), img->walk.words.begin(), img->walk.words.end());
+        }
     *out = mx;
     return MFA_OK;
 }
@@ -153,15 +186,16 @@ void mfa_mixed_destroy(mfa_mixed_t* mx) {
         (void)hipSetDevice(kv.first);
         mfa_mixed::Dev& d = kv.second;
         if (d.rs) (void)hipStreamSynchronize(d.rs);
-        if (d.ws) (void)hipStreamSynchronize(d.ws);
+        for (hipStream_t w : d.ws) if (w) (void)hipStreamSynchronize(w);
         if (d.d_tables) (void)hipFree(d.d_tables);
         if (d.d_regions) (void)hipFree(d.d_regions);
         for (uint32_t* p : d.d_spill) if (p) (void)hipFree(p);
         if (d.d_counters) (void)hipFree(d.d_counters);
-        for (hipEvent_t e : d.ev) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {d.ev_in, d.ev_out, d.ev_r0, d.ev_r1, d.ev_w1}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : d.ev_g) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : d.ev_w) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {d.ev_in, d.ev_r0, d.ev_end}) if (e) (void)hipEventDestroy(e);
         if (d.rs) (void)hipStreamDestroy(d.rs);
-        if (d.ws) (void)hipStreamDestroy(d.ws);
+        for (hipStream_t w : d.ws) if (w) (void)hipStreamDestroy(w);
     }
     if (cur >= 0) (void)hipSetDevice(cur);
     delete mx;
@@ -177,22 +211,26 @@ static int mixed_device(mfa_mixed* mx, int device, mfa_mixed::Dev** out) {
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     d.n_cus = prop.multiProcessorCount;
-    HIP_TRY(hipMalloc((void**)&d.d_tables, mx->words.size() * 4));
-    HIP_TRY(hipMemcpy(d.d_tables, mx->words.data(), mx->words.size() * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMalloc((void**)&d.d_counters, 64 * sizeof(unsigned long long)));
+    if (mx->table_ok) {
+        HIP_TRY(hipMalloc((void**)&d.d_tables, mx->words.size() * 4));
+        HIP_TRY(hipMemcpy(d.d_tables, mx->words.data(), mx->words.size() * 4, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipMalloc((void**)&d.d_counters, 64 * MIX_MAX_LAUNCHES * sizeof(unsigned long long)));
     HIP_TRY(hipStreamCreateWithFlags(&d.rs, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&d.ws, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&d.ev_in, &d.ev_out}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    for (hipEvent_t* e : {&d.ev_r0, &d.ev_r1, &d.ev_w1}) HIP_TRY(hipEventCreate(e));
+    for (hipStream_t& w : d.ws) HIP_TRY(hipStreamCreateWithFlags(&w, hipStreamNonBlocking));
+    for (hipEvent_t& e : d.ev_g) HIP_TRY(hipEventCreate(&e));
+    for (hipEvent_t& e : d.ev_w) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.ev_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreate(&d.ev_r0));
+    HIP_TRY(hipEventCreate(&d.ev_end));
+    d.cost.assign(mx->images.size(), 0.0f);
     auto ins = mx->dev.emplace(device, d);
     *out = &ins.first->second;
     return MFA_OK;
 }
 
-// One batch, n_images segments: strings seg_first[s] .. seg_first[s+1]-1 are matched against images[s] (the order of
-// mfa_mixed_create).  seg_first is a HOST array of n_images + 1 indices, seg_first[0] = 0, seg_first[n_images] = n.
-// The region pass runs group by group (runs of consecutive segments) on an internal stream, each group's walk on a second one as
-// soon as the group's regions are known: walks run beside the next group's region pass.  `stream` sees the call as one operation.
+// seg_first: HOST array of n_images + 1 string indices, seg_first[0] = 0, seg_first[n_images] = n: strings seg_first[s] ..
+// seg_first[s+1]-1 are matched against images[s] (the order of mfa_mixed_create).  `stream` sees the call as one operation.
 int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const uint64_t* seg_first,
                     uint8_t* d_results, int device, void* stream) {
     if (!mx || !d_offsets || !seg_first || (!d_results && n)) return MFA_ERR_INVALID_ARG;
@@ -206,73 +244,147 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
     int rc = mixed_device(mx, device, &d);
     if (rc != MFA_OK) return rc;
     hipStream_t cs = (hipStream_t)stream;
-    // groups: runs of consecutive segments, about n / G strings each, at most WALK_MAX_SEG segments
-    int G = env_int("MFA_MIXED_GROUPS", 3);
-    if (G < 1) G = 1;
-    std::vector<uint32_t> gb{0};                              // group g = segments gb[g] .. gb[g+1]-1
-    for (uint32_t s = 1; s < ns; s++) {
-        const uint32_t g = (uint32_t)gb.size();
-        const bool cut = seg_first[s] >= (n * g + G - 1) / G && g < (uint32_t)G;
-        if (cut || s - gb.back() >= WALK_MAX_SEG) gb.push_back(s);
+    const bool table = walk_selected() && mx->table_ok;
+    // groups: ranges of strings, cut at fractions of the batch (a segment may straddle a cut).  Decreasing sizes: the walk of the
+    // last group is what the call ends with.
+    std::vector<uint64_t> cut{0};
+    {
+        const char* spec = getenv("MFA_MIXED_CUTS");
+        if (!spec) spec = n >= 65536 ? "0.3,0.6,0.8,0.9" : "";
+        for (const char* q = spec; *q && cut.size() < MIX_MAX_GROUPS;) {
+            const uint64_t at = (uint64_t)((double)n * atof(q));
+            if (at > cut.back() && at < n) cut.push_back(at);
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        cut.push_back(n);
     }
-    gb.push_back(ns);
-    const uint32_t ng = (uint32_t)gb.size() - 1;
-    if (ng > 8) return MFA_ERR_UNSUPPORTED;
-    while (d->ev.size() < ng) {
-        hipEvent_t e;
-        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        d->ev.push_back(e);
-    }
+    const uint32_t ng = (uint32_t)cut.size() - 1;
     const char* re = getenv("MFA_REGIONS");
-    const bool with_regions = !(re && re[0] == '0');
+    const char* ae = getenv("MFA_ACCEL");
+    const bool with_regions = !(re && re[0] == '0') && !(ae && ae[0] == '0');
     if (with_regions) {
         rc = ctx_reserve((void**)&d->d_regions, &d->region_bytes, (size_t)n * MFA_REGION_WORDS * sizeof(uint64_t));
         if (rc != MFA_OK) return rc;
     }
+    int NW = env_int("MFA_MIXED_WALK_STREAMS", table ? 2 : 3);
+    if (NW < 1) NW = 1;
+    if (NW > (int)MIX_MAX_STREAMS) NW = MIX_MAX_STREAMS;
+    // which stream walks which segment (generated kernels): first call one after the other (timed), then by cost
+    std::vector<int> where(ns, 0);
+    const bool calibrating = !table && !d->calibrated;
+    if (!table && d->calibrated && d->ng_last == ng) {
+        // a segment's walk is released when the group that holds its first string is scanned (segments that straddle a cut are rare)
+        float free_at[MIX_MAX_STREAMS] = {0};
+        for (uint32_t s = 0, g = 0; s < ns; s++) {
+            while (g + 1 < ng && cut[g + 1] <= seg_first[s]) g++;
+            int best = 0;
+            for (int k = 1; k < NW; k++)
+                if (std::max(free_at[k], d->ready[g]) < std::max(free_at[best], d->ready[g])) best = k;
+            free_at[best] = std::max(free_at[best], d->ready[g]) + 1.5f * d->cost[s];      // beside the region pass a walk takes about 1.5 x its time alone
+            where[s] = best;
+        }
+    }
     HIP_TRY(hipEventRecord(d->ev_in, cs));
     HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_in, 0));
-    HIP_TRY(hipStreamWaitEvent(d->ws, d->ev_in, 0));
+    for (int k = 0; k < NW; k++) HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_in, 0));
     HIP_TRY(hipEventRecord(d->ev_r0, d->rs));
-    WalkPlanInput p{mx->K, mx->max_live, mx->reversed, (uint32_t)mx->words.size()};
+    bool used[MIX_MAX_STREAMS] = {false};
+    uint32_t slot = 0;                                        // table engine: launches of this call
     for (uint32_t g = 0; g < ng; g++) {
-        const uint64_t lo = seg_first[gb[g]], hi = seg_first[gb[g + 1]];
-        if (hi == lo) continue;
+        const uint64_t lo = cut[g], hi = cut[g + 1];
         if (with_regions) {
             rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d->d_regions + lo * MFA_REGION_WORDS, d->rs);
             if (rc != MFA_OK) return rc;
         }
-        HIP_TRY(hipEventRecord(d->ev[g], d->rs));
-        HIP_TRY(hipStreamWaitEvent(d->ws, d->ev[g], 0));
-        uint32_t sf[WALK_MAX_SEG + 1], stb[WALK_MAX_SEG];
-        const uint32_t nseg = gb[g + 1] - gb[g];
-        for (uint32_t k = 0; k <= nseg; k++) sf[k] = (uint32_t)(seg_first[gb[g] + k] - lo);
-        for (uint32_t k = 0; k < nseg; k++) stb[k] = mx->block_at[gb[g] + k];
-        rc = launch_walk(p, d->d_tables, d->n_cus, d_bytes, d_offsets + lo, hi - lo, d_results + lo,
-                         with_regions ? d->d_regions + lo * MFA_REGION_WORDS : nullptr, nseg, sf, stb, &d->d_spill[g], &d->spill_bytes[g],
-                         d->d_counters + g, d->ws);
-        if (rc != MFA_OK) return rc;
+        HIP_TRY(hipEventRecord(d->ev_g[g], d->rs));
+        const uint64_t* tab = with_regions ? d->d_regions : nullptr;
+        // the segments that overlap this group
+        uint32_t sa = 0;
+        while (sa + 1 < ns && seg_first[sa + 1] <= lo) sa++;
+        uint32_t sb = sa;
+        while (sb < ns && seg_first[sb] < hi) sb++;
+        bool waits[MIX_MAX_STREAMS] = {false};
+        if (table) {
+            // one launch per run of consecutive segments whose automata have the same number of cells (a launch's kernel and its LDS
+            // footprint are those of its largest cell count); groups alternate between the walk streams, so that a group's walk may
+            // start while the one before it drains
+            const int k = (int)(g % (uint32_t)NW);
+            for (uint32_t s0 = sa; s0 < sb;) {
+                uint32_t s1 = s0 + 1;
+                const uint32_t Kc = mx->K > 6 ? mx->K : mx->images[s0]->walk.K;
+                while (s1 < sb && s1 - s0 < WALK_MAX_SEG && (mx->K > 6 || mx->images[s1]->walk.K == Kc)) s1++;
+                const uint64_t a = std::max(seg_first[s0], lo), b = std::min(seg_first[s1], hi);
+                if (b > a) {
+                    if (slot >= MIX_MAX_LAUNCHES) return MFA_ERR_UNSUPPORTED;
+                    if (!waits[k]) { HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_g[g], 0)); waits[k] = true; }
+                    uint32_t sf[WALK_MAX_SEG + 1], stb[WALK_MAX_SEG], ml = 1;
+                    for (uint32_t j = 0; j <= s1 - s0; j++) sf[j] = (uint32_t)(std::min(std::max(seg_first[s0 + j], a), b) - a);
+                    // the launch gets the blocks of ITS automata only (they lie back to back): less LDS per workgroup
+                    const uint32_t w0 = mx->block_at[s0], w1 = s1 < ns ? mx->block_at[s1] : (uint32_t)mx->words.size();
+                    for (uint32_t j = 0; j < s1 - s0; j++) { stb[j] = mx->block_at[s0 + j] - w0; ml = std::max(ml, mx->images[s0 + j]->walk.max_live); }
+                    const WalkPlanInput pk{Kc, ml, mx->reversed, w1 - w0};
+                    rc = launch_walk(pk, d->d_tables + w0, d->n_cus, d_bytes, d_offsets + a, b - a, d_results + a, tab ? tab + a * MFA_REGION_WORDS : nullptr,
+                                     s1 - s0, sf, stb, &d->d_spill[slot], &d->spill_bytes[slot], d->d_counters + 64 * slot, d->ws[k]);
+                    if (rc != MFA_OK) return rc;
+                    slot++;
+                    used[k] = true;
+                }
+                s0 = s1;
+            }
+        } else {
+            for (uint32_t s = sa; s < sb; s++) {
+                const uint64_t a = std::max(seg_first[s], lo), b = std::min(seg_first[s + 1], hi);
+                if (b <= a) continue;
+                const int k = where[s];
+                if (!waits[k]) { HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_g[g], 0)); waits[k] = true; }
+                rc = mfa_match_batch_regions(mx->images[s], d_bytes, d_offsets + a, b - a, d_results + a, tab ? tab + a * MFA_REGION_WORDS : nullptr, device, d->ws[k]);
+                if (rc != MFA_OK) return rc;
+                used[k] = true;
+            }
+        }
     }
-    HIP_TRY(hipEventRecord(d->ev_r1, d->rs));
-    HIP_TRY(hipEventRecord(d->ev_w1, d->ws));
-    HIP_TRY(hipEventRecord(d->ev_out, d->ws));
-    HIP_TRY(hipStreamWaitEvent(cs, d->ev_out, 0));
-    HIP_TRY(hipStreamWaitEvent(cs, d->ev_r1, 0));
+    // the caller's stream (and the call's end event, on the region stream) wait for every stream that was given work
+    for (int k = 0; k < NW; k++)
+        if (used[k]) {
+            HIP_TRY(hipEventRecord(d->ev_w[k], d->ws[k]));
+            HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_w[k], 0));
+        }
+    HIP_TRY(hipEventRecord(d->ev_end, d->rs));
+    HIP_TRY(hipStreamWaitEvent(cs, d->ev_end, 0));
     d->timed = true;
+    d->ng_last = ng;
+    if (calibrating) {                                        // once per device: the walks' costs and the groups' region times
+        HIP_TRY(hipEventSynchronize(d->ev_end));
+        for (uint32_t s = 0; s < ns; s++) {
+            float ms = 0.0f;
+            if (seg_first[s + 1] > seg_first[s] && mfa_last_kernel_ms(mx->images[s], device, &ms) == MFA_OK) d->cost[s] = ms;
+        }
+        float prev = 0.0f;
+        for (uint32_t g = 0; g < ng; g++) {
+            // the calibration pass runs a group's walks before the next group's region launch is reached by nothing: region launches
+            // follow each other on their own stream, so the elapsed time between two group events is the later group's region time
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev_r0, d->ev_g[g]));
+            d->ready[g] = ms; prev = ms;
+        }
+        (void)prev;
+        d->calibrated = true;
+    }
     return MFA_OK;
 }
 
-// Device time of the last mfa_match_mixed on `device`: the region launches (first to last, on their stream) and the whole call
-// (first region launch to last walk).  Synchronises on the call's last events.
+// Device time of the last mfa_match_mixed on `device`: from its first region launch to the end of its last region launch, and to
+// the end of its last walk (either pointer may be NULL).  Synchronises on the call's end.
 int mfa_mixed_last_ms(mfa_mixed_t* mx, int device, float* region_ms, float* span_ms) {
     if (!mx) return MFA_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(mx->mu);
     auto it = mx->dev.find(device);
     if (it == mx->dev.end() || !it->second.timed) return MFA_ERR_INVALID_ARG;
     mfa_mixed::Dev& d = it->second;
-    HIP_TRY(hipEventSynchronize(d.ev_w1));
-    HIP_TRY(hipEventSynchronize(d.ev_r1));
-    if (region_ms) HIP_TRY(hipEventElapsedTime(region_ms, d.ev_r0, d.ev_r1));
-    if (span_ms) HIP_TRY(hipEventElapsedTime(span_ms, d.ev_r0, d.ev_w1));
+    HIP_TRY(hipEventSynchronize(d.ev_end));
+    if (region_ms) HIP_TRY(hipEventElapsedTime(region_ms, d.ev_r0, d.ev_g[d.ng_last ? d.ng_last - 1 : 0]));
+    if (span_ms) HIP_TRY(hipEventElapsedTime(span_ms, d.ev_r0, d.ev_end));
     return MFA_OK;
 }
 

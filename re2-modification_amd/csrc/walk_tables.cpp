@@ -183,7 +183,7 @@ int build_walk_tables(const HostImage& img, WalkTables& out, bool wide) {
     };
     for (const auto& v : vn) {
         const uint32_t id = vid.at(std::make_pair(v.node, v.mask));
-        w[off_vinfo + id] = 1u | (v.has_eps ? 2u : 0u) | (v.c_acc ? 4u : 0u) | (v.qualifies ? 8u : 0u) | (fname_of(v.mask) << 4) | (v.mask << 8);
+        w[off_vinfo + id] = 1u | (v.has_eps ? 2u : 0u) | (v.c_acc ? 4u : 0u) | (v.qualifies ? 8u : 0u) | (fname_of(v.mask) << 4) | (v.mask << 8) | (v.c.empty() ? 0u : 1u << 17);
         if (v.c.size() >= 4096 || n_ee >= (1u << 20)) return MFA_ERR_UNSUPPORTED;
         w[off_vc + id] = (n_ee << 12) | (uint32_t)v.c.size();
         for (const auto& e : v.c) put(e);

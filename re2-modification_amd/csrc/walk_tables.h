@@ -30,7 +30,7 @@ struct HostImage;
 // vid = node << vb | variant.  Unused (node, variant) slots have vinfo = 0 and are never reached.
 // vinfo: bit 0 valid | bit 1 has_eps (A: accept when pos == len) | bit 2 c_acc (an epsilon edge behind absent-cell edges)
 //        | bit 3 qualifies (a waiting state is carried: mfa.cpp:195-197) | bits 4..7 fname (lowest present cell, 0 = none)
-//        | bits 8..16 mask (cells present, bit c-1)
+//        | bits 8..16 mask (cells present, bit c-1) | bit 17 the vnode has waiting insertions (vc)
 // vc / vb: begin << 12 | count   (begin in effective edges, count < 4096)
 // effective edge, word 0: bit 0 kind (0 = literal / waiting insertion, 1 = cell read) | bits 1..4 cell (0-based) of a read
 //        | bits 5..8 fname of the target vnode | bits 9..31 target vid

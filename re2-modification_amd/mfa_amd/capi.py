@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "csrc", "libmfa_hip.so")
+LIB_PATH = os.environ.get("MFA_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libmfa_hip.so")      # (the override: development builds)
 
 OK = 0
 KERNEL_NONE, KERNEL_GENERIC, KERNEL_SPECIALISED, KERNEL_TABLE, KERNEL_WALK = 0, 1, 2, 3, 4

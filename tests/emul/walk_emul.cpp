@@ -80,7 +80,8 @@ static void run(const Batch& b, const std::vector<uint32_t>& T, uint32_t C, uint
     const uint32_t CX = CM > C ? CM - C : 1u;
     std::vector<uint32_t> lv(2 * C * Lay<K>::W, 0xdeadbeefu), ld(2 * C * Lay<K>::DW, 0xdeadbeefu), sb(C * Lay<K>::W, 0xdeadbeefu), sa(C * Lay<K>::DW, 0xdeadbeefu),
         gv(2 * CX * Lay<K>::W, 0xdeadbeefu), gd(2 * CX * Lay<K>::DW, 0xdeadbeefu), gsb(CX * Lay<K>::W, 0xdeadbeefu), gsa(CX * Lay<K>::DW, 0xdeadbeefu);
-    Store st{lv.data(), ld.data(), sb.data(), sa.data(), gv.data(), gd.data(), gsb.data(), gsa.data(), C, CX};
+    Store st;
+    st.lv = lv.data(); st.ld = ld.data(); st.sb = sb.data(); st.sa = sa.data(); st.gv = gv.data(); st.gd = gd.data(); st.gsb = gsb.data(); st.gsa = gsa.data(); st.C = C; st.CX = CX;
     uint64_t rtc[MFA_RT_CACHED] = {0};
     SeqFeeder feed;
     feed.n = b.n;
@@ -142,6 +143,6 @@ int main(int argc, char** argv) {
     for (uint64_t k = 0; k < n; k++) { putchar('0' + res[k]); putchar('\n'); }
     fprintf(stderr, "emul: %llu strings, steps %llu, dual %llu, probes %llu, hits %llu, skipped %llu, spill-steps %llu\n", (unsigned long long)n, ws.steps, ws.dual,
             ws.probes, ws.hits, ws.skipped, ws.spills);
-    if (getenv("EMUL_HIST")) { for (int k = 0; k < 80; k++) if (ws.hist[k]) fprintf(stderr, " n=%d:%llu", k, ws.hist[k]); fprintf(stderr, "\n"); }
+    if (getenv("EMUL_HIST")) { fprintf(stderr, "events: entries %llu edge-evals %llu inserts %llu search-iters %llu c-items %llu\n", g_ev[0], g_ev[1], g_ev[2], g_ev[3], g_ev[6]); for (int k = 0; k < 80; k++) if (ws.hist[k]) fprintf(stderr, " n=%d:%llu", k, ws.hist[k]); fprintf(stderr, "\n"); }
     return 0;
 }

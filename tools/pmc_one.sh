@@ -12,6 +12,6 @@ import csv, glob, collections
 tot = collections.defaultdict(float)
 for f in glob.glob("$R/gpurun_out/pmc_one/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("mfa_jit_kernel"): tot[r["Counter_Name"]] += float(r["Counter_Value"])
+        if "${KERNEL:-mfa_jit_kernel}" in r["Kernel_Name"]: tot[r["Counter_Name"]] += float(r["Counter_Value"])
 for k in sorted(tot): print(k, tot[k])
 PY

@@ -66,7 +66,7 @@ def timing(n_per=125000):
         nb = int(o[-1].item())
         blob = image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex))
         res = {}
-        for mode in ("jit", "table"):
+        for mode in (() if os.environ.get("SKIP_PER_EX") else ("jit", "table")):
             os.environ["MFA_WALK"] = mode
             img = capi.Image(blob)
             r = torch.empty(n_per, dtype=torch.uint8, device=dev)
@@ -76,38 +76,39 @@ def timing(n_per=125000):
             torch.cuda.synchronize()
             res[mode] = (ms[-1], r.clone())
             imgs.setdefault(ex, img) if mode == "table" else None
-        same = bool(torch.equal(res["jit"][1], res["table"][1]))
-        print("ex%-2d %6.0f MB  jit walk %.3f ms  table walk %.3f ms  region %.3f ms  same=%s accepted=%d" % (
+        if res:
+          same = bool(torch.equal(res["jit"][1], res["table"][1]))
+          print("ex%-2d %6.0f MB  jit walk %.3f ms  table walk %.3f ms  region %.3f ms  same=%s accepted=%d" % (
             ex, nb / 1e6, res["jit"][0][0], res["table"][0][0], res["table"][0][1], same, int(res["table"][1].sum())), flush=True)
         parts_b.append(b[:nb]); parts_o.append(o[:-1] + pos_b); pos_b += nb; seg.append(seg[-1] + n_per)
         del b, o
-    os.environ["MFA_WALK"] = "table"
     bytes_all = torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=dev)])
     off_all = torch.cat(parts_o + [torch.tensor([pos_b], dtype=torch.int64, device=dev)])
     del parts_b, parts_o
-    mx = capi.Mixed([imgs[ex] for ex in layout])
-    res = torch.zeros(seg[-1], dtype=torch.uint8, device=dev)
-    for groups in ("1", "2", "3", "4", "5"):
-        os.environ["MFA_MIXED_GROUPS"] = groups
-        t = []
-        for _ in range(6):
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            mx.match_tensors(bytes_all, off_all, seg, res); torch.cuda.synchronize()
-            t.append((time.perf_counter() - t0) * 1e3)
-        r_ms, sp_ms = mx.last_ms(0)
-        print("mixed groups=%s: wall %.3f ms (min of 6: %.3f)  region %.3f  span %.3f  -> %.0f GB/s  frac %.3f" % (
-            groups, t[-1], min(t[1:]), r_ms, sp_ms, pos_b / (min(t[1:]) * 1e-3) / 1e9, pos_b / (min(t[1:]) * 1e-3) / 1e9 / 8000), flush=True)
-    # parity of the mixed call with the per-example results
-    at = 0
-    ok = True
+    # reference answers: every example by itself, generated kernels
+    os.environ["MFA_WALK"] = "jit"
+    ref = torch.zeros(seg[-1], dtype=torch.uint8, device=dev)
     for k, ex in enumerate(layout):
-        os.environ["MFA_WALK"] = "jit"
         img = capi.Image(image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex)))
         a, b2 = seg[k], seg[k + 1]
-        r = img.match_tensors(bytes_all, off_all[a:b2 + 1]); torch.cuda.synchronize()
-        if not torch.equal(r, res[a:b2]):
-            ok = False; print("mixed differs from jit on ex", ex, int((r != res[a:b2]).sum()))
-    print("mixed == per-example jit results:", ok, flush=True)
+        img.match_tensors(bytes_all, off_all[a:b2 + 1], ref[a:b2]); torch.cuda.synchronize()
+    for engine in os.environ.get("ENGINES", "jit,table").split(","):
+        os.environ["MFA_WALK"] = engine
+        ims = [capi.Image(image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex))) for ex in layout]
+        for groups in os.environ.get("CUTS", "0.3,0.6,0.8,0.9|0.4,0.7,0.9|0.25,0.5,0.7,0.85,0.95").split("|"):
+            os.environ["MFA_MIXED_CUTS"] = groups
+            mx = capi.Mixed(ims)
+            res = torch.zeros(seg[-1], dtype=torch.uint8, device=dev)
+            t = []
+            for _ in range(8):
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                mx.match_tensors(bytes_all, off_all, seg, res); torch.cuda.synchronize()
+                t.append((time.perf_counter() - t0) * 1e3)
+            r_ms, sp_ms = mx.last_ms(0)
+            best = min(t[2:])
+            print("mixed %-5s cuts=%s: wall %.3f ms (best of 6)  regions done at %.3f  span %.3f  -> %.0f GB/s  frac %.3f  same=%s" % (
+                engine, groups, best, r_ms, sp_ms, pos_b / (best * 1e-3) / 1e9, pos_b / (best * 1e-3) / 1e9 / 8000, bool(torch.equal(res, ref))), flush=True)
+            mx.close()
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["parity", "timing"]
