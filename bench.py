@@ -2,10 +2,10 @@
 """Benchmark of the match path: input GB/s on the 10-example attack corpus (BASELINE.json metric).
 
 One step = one pass of the hot path over this rank's shard of the mixed corpus (BASELINE configs[3]): ONE batch
-(one byte buffer, one offset array) that holds the strings of all ten README examples, example after example.
-Per step and per example: one launch of the region pre-pass (region_scan_kernel, mfa_region_scan) on the region
-stream and one launch of the example's walk kernel (mfa_match_batch_regions) on a walk stream that waits for it;
-then the result bitmap of the shard is gathered to rank 0 (RCCL when N > 1).
+(one byte buffer, one offset array) that holds the strings of all ten README examples, example after example,
+matched by ONE library call (mfa_match_mixed: the region pre-pass over groups of strings and the walks of every
+group beside the next group's pre-pass, scheduled inside the library); then the result bitmap of the shard is
+gathered to rank 0 (RCCL when N > 1).
 Per-GPU work is fixed (weak scaling): rank r holds `--strings-per-example` strings of every example,
 `prefix + pumped_string(n, pump) [+ suffix]` with n log-uniform in [--min-len, --max-len]
 (generator: reference matchers/example_runner.cpp:15-29), generated on the device before the timed
@@ -29,9 +29,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "re2-modification_amd"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
-PARITY_N = 48                  # strings per example whose GPU answers are re-checked on the CPU after the timed region
+KERNEL_NAMES = {1: "walk_kernel (table-driven)", 2: "mfa_jit_kernel (generated for the automaton)", 3: "dfa_tiled_kernel"}
+PARITY_FRACTION = 0.01         # seeded sample of every example's shard (no length cap) re-checked on the CPU after the timed region
+BASELINE_N = 48                # first strings of every example kept on the host for the reference-build baseline
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02f_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
 
 
 def spawn_ranks(args):
@@ -44,6 +46,14 @@ def spawn_ranks(args):
         sys.stderr.write("bench.py: --gpus %d but %d device(s) visible; MFA_BENCH_REHEARSE=1 runs the ranks on one GPU over gloo\n"
                          % (args.gpus, n_dev))
         return 2
+    # preflight, before anything is forked: the native library loads and exports what this script calls; with the generated
+    # kernels asked for, every example's code object is in the cache (host-only work: N ranks must not meet on a cold compiler)
+    sys.path.insert(0, os.path.join(ROOT, "re2-modification_amd"))
+    from mfa_amd import capi, corpus
+    capi.lib()
+    if args.engine == "jit" or env.get("MFA_WALK") == "jit":
+        for ex in corpus.EXAMPLES:
+            capi.Image(load_blob("ex%d_plain" % ex)).specialize()
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -54,9 +64,27 @@ def spawn_ranks(args):
         e = dict(env)
         e.update({"RANK": str(r), "LOCAL_RANK": str(r)})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    # wait for every rank; one that fails or does not finish in time takes its siblings down (exact pids, never a pattern)
+    deadline = time.monotonic() + float(env.get("MFA_BENCH_RANK_TIMEOUT", "1500"))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            try:
+                code = p.wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.remove(p)
+            rc = max(rc, abs(code))
+        if pending and (rc != 0 or time.monotonic() > deadline):
+            if rc == 0:
+                sys.stderr.write("bench.py: a rank did not finish in time\n")
+                rc = 124
+            for p in pending:
+                p.kill()
+            for p in pending:
+                p.wait()
+            break
     return rc
 
 
@@ -109,13 +137,13 @@ def cpu_baseline(corpus, shards, gpu_results, budget_strings=8, cap=32768):
                 return None
             f = p.stdout.split()
             n_str += int(f[0]); tot_bytes += int(f[1]); tot_sec += float(f[2]); acc_cpu += int(f[3])
-        # wider parity check with the CPU restatement (fast): the first PARITY_N strings of every example
+        # the CPU restatement timed on the same sample (1 thread, then every core)
         checked, mism, port_bytes, port_sec = 0, 0, 0, 0.0
         all_cores = None
         if os.path.exists(cli):
             jobs = []
             for ex, sh in shards.items():
-                sample = [s for s in sh["sample"] if len(s) <= 32768]
+                sample = [s for s in sh["sample"] if len(s) <= 32768]      # (timing sample; the parity sample is parity_sample())
                 idx = [k for k, s in enumerate(sh["sample"]) if len(s) <= 32768]
                 blob_path = os.path.join(tmp, "p%d.blob" % ex)
                 with open(blob_path, "wb") as f:
@@ -166,6 +194,51 @@ def cpu_baseline(corpus, shards, gpu_results, budget_strings=8, cap=32768):
             "restatement_all_cores": all_cores}
 
 
+# ---- parity at scale: a seeded sample of the batch against the CPU restatement, every host core ----------------------
+def _oracle_match(args):
+    cli, blob_path, text = args
+    p = subprocess.run([cli, "match", blob_path], input=text, capture_output=True)
+    if p.returncode != 0:
+        return None
+    return [int(x) for x in p.stdout.split()]
+
+
+def parity_sample(jobs, cores=None):
+    """jobs: list of (blob, strings, gpu answers).  The CPU restatement (oracle/oracle_cli, test infrastructure: the checker,
+    never the thing measured) on every string, one process per core; returns {strings, bytes, max_len, mismatches}."""
+    cli = os.path.join(ROOT, "oracle", "oracle_cli")
+    if not os.path.exists(cli):
+        return None
+    cores = cores or max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32))
+    from concurrent.futures import ThreadPoolExecutor
+    t0 = time.perf_counter()
+    n_str = n_bytes = max_len = mism = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        work, owners = [], []
+        for j, (blob, strings, got) in enumerate(jobs):
+            path = os.path.join(tmp, "j%d.blob" % j)
+            with open(path, "wb") as f:
+                f.write(blob)
+            # longest first, dealt round-robin: the cores finish together
+            order = sorted(range(len(strings)), key=lambda k: -len(strings[k]))
+            for c in range(cores):
+                idx = order[c::cores]
+                if idx:
+                    work.append((cli, path, b"".join(strings[k] + b"\n" for k in idx)))
+                    owners.append((j, idx))
+            n_str += len(strings); n_bytes += sum(len(x) for x in strings); max_len = max([max_len] + [len(x) for x in strings])
+        with ThreadPoolExecutor(max_workers=cores) as pool:
+            outs = list(pool.map(_oracle_match, work))
+        for (j, idx), out in zip(owners, outs):
+            got = jobs[j][2]
+            if out is None or len(out) != len(idx):
+                mism += len(idx)
+                continue
+            mism += sum(1 for k, w in zip(idx, out) if int(got[k]) != w)
+    return {"strings": n_str, "bytes": n_bytes, "max_len": max_len, "mismatches": mism, "cores": cores,
+            "seconds": time.perf_counter() - t0, "checker": "oracle/oracle_cli (CPU restatement, pinned against the reference's own answers by tests/golden)"}
+
+
 # ---- secondary lines (other BASELINE configs; rank 0, N = 1 only) --------------------------------------------------
 def _timed(img, flat, off, res, device, reps=3):
     import numpy as np
@@ -207,28 +280,30 @@ def secondary_dfa(device, capi, n_strings=1 << 20, length=1024):
             "results_exact": ok}
 
 
-def secondary_config3(device, capi, n_strings=1 << 17, length=65536):
-    """BASELINE.json configs[2] (roofline variant of SURVEY section 8d): example 1, strings of exactly 64 KiB, mix by
-    j mod 4: a^(L-1) b, a^L, a^L with one byte at a seeded position set to b, i.i.d. {a: 0.99, b: 0.01}."""
+def secondary_config3(device, capi, n_strings=1 << 20, length=65536):
+    """BASELINE.json configs[2] at its full size (roofline variant of SURVEY section 8d): example 1, 1M strings of exactly 64 KiB
+    (68.7 GB), mix by j mod 4: a^(L-1) b, a^L, a^L with one byte at a seeded position set to b, i.i.d. {a: 0.99, b: 0.01}."""
+    import numpy as np
     import torch
     blob = load_blob("ex1_plain")
     img = capi.Image(blob)
     g = torch.Generator(device=device); g.manual_seed(0x5EED0003)
-    data = torch.full((n_strings, length), ord("a"), dtype=torch.uint8, device=device)
+    flat = torch.empty(n_strings * length + 64, dtype=torch.uint8, device=device)
+    flat.fill_(ord("a"))
+    flat[-64:] = 0
+    data = flat[:n_strings * length].view(n_strings, length)
     data[0::4, -1] = ord("b")
     rows = torch.arange(2, n_strings, 4, device=device)
     data[rows, torch.randint(0, length, (rows.numel(),), generator=g, device=device)] = ord("b")
-    for lo in range(3, n_strings, 4 * 4096):                      # the random rows, in chunks
-        r = torch.arange(lo, min(n_strings, lo + 4 * 4096), 4, device=device)
-        mask = torch.rand((r.numel(), length), generator=g, device=device) < 0.01
-        data[r] = torch.where(mask, torch.tensor(ord("b"), dtype=torch.uint8, device=device), data[r])
+    noise = data.view(n_strings // 4, 4, length)[:, 3, :]          # the random rows: a strided view, filled in place, in chunks
+    for lo in range(0, n_strings // 4, 4096):
+        hi = min(n_strings // 4, lo + 4096)
+        mask = torch.rand((hi - lo, length), generator=g, device=device) < 0.01
+        noise[lo:hi].masked_fill_(mask, ord("b"))
         del mask
-    short = [bytes(data[k, :3000].cpu().numpy().tobytes()) for k in range(8)]
-    flat = torch.cat([data.reshape(-1), torch.zeros(64, dtype=torch.uint8, device=device)])
-    del data
     off = torch.arange(0, (n_strings + 1) * length, length, dtype=torch.int64, device=device)
     res = torch.empty(n_strings, dtype=torch.uint8, device=device)
-    t, tr = _timed(img, flat, off, res, device)
+    t, tr = _timed(img, flat, off, res, device, reps=2)
     nbytes = n_strings * length
     # the region pass stops reading a string once its table is full (64 candidates: text made of hundreds of medium runs, here the
     # a/b noise strings): those strings' bytes are only partly touched
@@ -237,13 +312,14 @@ def secondary_config3(device, capi, n_strings=1 << 17, length=65536):
     del tab
     # a^L is accepted (SURVEY section 8c anchors: aa, aaa, aaaa, aaaaaaaa -> 1), every string containing a b is not
     ok = bool(res[1::4].all().item()) and not bool(res[0::4].any().item()) and not bool(res[2::4].any().item()) and not bool(res[3::4].any().item())
-    import oracle_lib
-    data_s, off_s = oracle_lib.pack(short)
-    import numpy as np
-    d_b = torch.zeros(len(data_s) + 64, dtype=torch.uint8, device=device); d_b[:len(data_s)] = torch.from_numpy(data_s.copy())
-    got = img.match_tensors(d_b, torch.from_numpy(off_s.astype(np.int64)).to(device)).cpu().numpy()
-    return {"workload": "configs[2]: ({a*}:1&1)*, %d strings of exactly %d bytes, 4-way attack mix" % (n_strings, length),
-            "kernel": "region_scan_kernel + mfa_jit_kernel", "region_ms": tr, "walk_ms": t, "GB/s_on_sum_of_lengths": nbytes / ((t + tr) * 1e-3) / 1e9,
+    # parity: a seeded 0.1 % of the strings, full length, against the CPU restatement
+    rng = np.random.Generator(np.random.Philox(0x5EED0013))
+    idx = np.sort(rng.choice(n_strings, size=max(8, n_strings // 1024), replace=False))
+    strings = [bytes(data[int(k)].cpu().numpy().tobytes()) for k in idx]
+    par = parity_sample([(blob, strings, res[torch.from_numpy(idx).to(device)].cpu().numpy())])
+    return {"workload": "configs[2]: ({a*}:1&1)*, %d strings of exactly %d bytes (%.1f GB), 4-way attack mix" % (n_strings, length, nbytes / 1e9),
+            "kernel": "region_scan_kernel + " + KERNEL_NAMES.get(img.info()["last_kernel"], "?"), "region_ms": tr, "walk_ms": t,
+            "GB/s_on_sum_of_lengths": nbytes / ((t + tr) * 1e-3) / 1e9,
             # the walk stops at the first empty state set (mfa.cpp:224-225), but the region pass has read every byte by then
             "touched_bytes": {"at_least": nbytes - cut * length, "at_most": nbytes},
             "touched_by": "region_scan_kernel reads every byte of every string except %d strings (%.1f %%) whose region table filled up, which it "
@@ -251,30 +327,50 @@ def secondary_config3(device, capi, n_strings=1 << 17, length=65536):
             "frac_of_hbm_peak_on_touched_bytes": {"at_least": (nbytes - cut * length) / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                   "at_most": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS},
             "region_pass_GB/s": nbytes / (tr * 1e-3) / 1e9 if tr > 0 else None,
-            "results_as_expected": ok, "parity_oracle_sample": _oracle_sample(blob, short, got)}
+            "results_as_expected": ok, "parity_sample": par}
 
 
 def secondary_64k_all_examples(device, capi, corpus, n_strings=16384):
     """north_star: "at 64 KiB strings" -- all ten examples, every string pumped to 64 KiB (pump size 65536), alternating
-    with / without suffix; per example region pass + walk, back to back."""
+    with / without suffix: ONE mixed batch through the same mfa_match_mixed call as the headline."""
     import numpy as np
     import torch
-    out = {"workload": "north_star size: 10 examples, %d strings each, pump size exactly 65536, alternating with/without suffix" % n_strings,
-           "kernel": "region_scan_kernel + mfa_jit_kernel, per example, back to back on one stream", "per_example": {}}
-    tot_b, tot_ms = 0, 0.0
-    for ex in sorted(corpus.EXAMPLES):
-        img = capi.Image(load_blob("ex%d_plain" % ex))
-        sizes = np.full(n_strings, 65536, dtype=np.int64)
-        flat, off = corpus.device_batch(ex, sizes, (np.arange(n_strings) % 2) == 0, device)
-        res = torch.empty(n_strings, dtype=torch.uint8, device=device)
-        t, tr = _timed(img, flat, off, res, device, reps=2)
-        nb = int(off[-1].item())
-        out["per_example"][str(ex)] = {"bytes": nb, "region_ms": tr, "walk_ms": t, "GB/s": nb / ((t + tr) * 1e-3) / 1e9, "accepted": int(res.sum().item())}
-        tot_b += nb; tot_ms += t + tr
-        del flat, off, res
-    out["GB/s"] = tot_b / (tot_ms * 1e-3) / 1e9
-    out["touched_bytes"] = tot_b
-    out["frac_of_hbm_peak_on_touched_bytes"] = out["GB/s"] / HBM_PEAK_GBS
+    layout = [2, 5, 3, 8, 9, 10, 6, 4, 1, 7]
+    parts_b, parts_o, seg, pos_b, images, blobs = [], [], [0], 0, [], []
+    sizes = np.full(n_strings, 65536, dtype=np.int64)
+    ws = (np.arange(n_strings) % 2) == 0
+    for ex in layout:
+        b, o = corpus.device_batch(ex, sizes, ws, device)
+        nb = int(o[-1].item())
+        parts_b.append(b[:nb]); parts_o.append(o[:-1] + pos_b); pos_b += nb; seg.append(seg[-1] + n_strings)
+        blobs.append(load_blob("ex%d_plain" % ex))
+        images.append(capi.Image(blobs[-1]))
+        del b, o
+    bytes_all = torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=device)])
+    off_all = torch.cat(parts_o + [torch.tensor([pos_b], dtype=torch.int64, device=device)])
+    del parts_b, parts_o
+    mx = capi.Mixed(images)
+    res = torch.zeros(seg[-1], dtype=torch.uint8, device=device)
+    wall, spans, regs = [], [], []
+    for _ in range(6):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        mx.match_tensors(bytes_all, off_all, seg, res); torch.cuda.synchronize()
+        wall.append((time.perf_counter() - t0) * 1e3)
+        r_ms, sp_ms = mx.last_ms(device.index or 0)
+        spans.append(sp_ms); regs.append(r_ms)
+    span = float(np.mean(spans[2:]))
+    # parity: 1 % of every example's strings (they are all of the full size) against the CPU restatement
+    rng = np.random.Generator(np.random.Philox(0x5EED0014))
+    jobs = []
+    for k, ex in enumerate(layout):
+        idx = np.sort(rng.choice(n_strings, size=max(4, n_strings // 100), replace=False))
+        jobs.append((blobs[k], corpus.host_strings(ex, sizes[idx], ws[idx]), res[seg[k] + torch.from_numpy(idx).to(device)].cpu().numpy()))
+    out = {"workload": "north_star size: 10 examples as one mixed batch, %d strings each, pump size exactly 65536, alternating with/without suffix" % n_strings,
+           "kernel": "mfa_match_mixed: region_scan_kernel + " + KERNEL_NAMES.get(images[0].info()["last_kernel"], "walk_kernel"),
+           "bytes": pos_b, "span_ms": span, "region_ms": float(np.mean(regs[2:])), "wall_ms": float(np.mean(wall[2:])),
+           "GB/s": pos_b / (span * 1e-3) / 1e9, "touched_bytes": pos_b, "frac_of_hbm_peak_on_touched_bytes": pos_b / (span * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "accepted": int((res == 1).sum().item()), "parity_sample": parity_sample(jobs)}
+    mx.close()
     return out
 
 
@@ -312,7 +408,7 @@ def secondary_no_regions(device, capi, corpus, n_strings=262144, length=4096):
         d_s = torch.zeros(len(ds) + 64, dtype=torch.uint8, device=device); d_s[:len(ds)] = torch.from_numpy(ds.copy())
         got = img.match_tensors(d_s, torch.from_numpy(os_.astype(np.int64)).to(device)).cpu().numpy()
         lines.append({"workload": "non-periodic text, example %d, %d strings of %d bytes (64 distinct)" % (ex, n_strings, length),
-                      "kernel": "region_scan_kernel + mfa_jit_kernel", "region_ms": tr, "walk_ms": t, "GB/s": nb / ((t + tr) * 1e-3) / 1e9,
+                      "kernel": "region_scan_kernel + " + KERNEL_NAMES.get(img.info()["last_kernel"], "?"), "region_ms": tr, "walk_ms": t, "GB/s": nb / ((t + tr) * 1e-3) / 1e9,
                       "char_steps_per_s": nb / ((t + tr) * 1e-3), "accepted": int(res.sum().item()),
                       "parity_oracle_sample": _oracle_sample(blob, short, got)})
         del d_b, d_o, res
@@ -328,21 +424,22 @@ def secondary_no_regions(device, capi, corpus, n_strings=262144, length=4096):
         ms.append(img.last_kernel_ms(device.index or 0))
     nb = int(off[-1].item())
     t = float(np.mean(ms[1:]))
-    lines.append({"workload": "example 1, %d attack strings of 4 KiB, NO region table (every step executed)" % n1, "kernel": "mfa_jit_kernel",
+    lines.append({"workload": "example 1, %d attack strings of 4 KiB, NO region table (every step executed)" % n1, "kernel": KERNEL_NAMES.get(img.info()["last_kernel"], "?"),
                   "walk_ms": t, "GB/s": nb / (t * 1e-3) / 1e9, "char_steps_per_s": nb / (t * 1e-3), "accepted": int(res.sum().item())})
     return lines
 
 
 def secondary_config5(device, capi, corpus, n_strings=125000):
     """BASELINE.json configs[4]: reversed MFAs (`-reverse`, is_reversed = 1) of the nondeterministic examples 3, 6, 8 on
-    pump-only strings (full walk) and pump+suffix strings (early exit), reported separately."""
+    pump-only strings (full walk) and pump+suffix strings (early exit), reported separately; 1 % of the strings of every line,
+    whatever their length, against the CPU restatement."""
     import numpy as np
     import torch
     out = []
     for ex in (3, 6, 8):
         blob = load_blob("ex%d_reverse" % ex)
         img = capi.Image(blob)
-        n = n_strings if ex != 8 else n_strings // 5
+        n = n_strings
         for tag, suffix in (("pump only", False), ("pump + suffix", True)):
             sizes = corpus.pump_sizes(n, 0x5EED0005 + ex, 1024, 65536)
             ws = np.full(n, suffix)
@@ -350,15 +447,15 @@ def secondary_config5(device, capi, corpus, n_strings=125000):
             res = torch.empty(n, dtype=torch.uint8, device=device)
             t, tr = _timed(img, flat, off, res, device, reps=2)
             nbytes = int(off[-1].item())
-            short = [k for k in range(n) if sizes[k] <= 2500][:24]
-            strings = corpus.host_strings(ex, sizes[short], ws[short])
+            rng = np.random.Generator(np.random.Philox(0x5EED0015 + ex))
+            idx = np.sort(rng.choice(n, size=max(4, n // 100), replace=False))
+            par = parity_sample([(blob, corpus.host_strings(ex, sizes[idx], ws[idx]), res[torch.from_numpy(idx).to(device)].cpu().numpy())])
             out.append({"workload": "configs[4]: example %d -reverse, %d strings, %s" % (ex, n, tag),
-                        "kernel": {capi.KERNEL_GENERIC: "mfa_walk_kernel", capi.KERNEL_SPECIALISED: "region_scan_kernel + mfa_jit_kernel"}[img.info()["last_kernel"]],
+                        "kernel": "region_scan_kernel + " + KERNEL_NAMES.get(img.info()["last_kernel"], "?"),
                         "region_ms": tr, "walk_ms": t, "GB/s": nbytes / ((t + tr) * 1e-3) / 1e9,
                         "touched_bytes": nbytes, "touched_by": "region pass reads every byte; the walk may exit early",
                         "frac_of_hbm_peak_on_touched_bytes": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "accepted": int(res.sum().item()),
-                        "parity_oracle_sample": _oracle_sample(blob, strings, res[short].cpu().numpy())})
+                        "accepted": int(res.sum().item()), "parity_sample": par})
             del flat, off, res
     return out
 
@@ -372,17 +469,16 @@ def main():
                     help="strings of each example per GPU (125000 x 10 examples x 8 GPUs = the 10M-string batch)")
     ap.add_argument("--min-len", type=int, default=1024)
     ap.add_argument("--max-len", type=int, default=65536)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every rank generates --strings-per-example strings of each example (fixed work per GPU); strong: ONE batch of "
+                         "10 x --strings-per-example strings is cut into --gpus ranges of about equal bytes (sharding.partition_by_bytes) and "
+                         "every rank generates and matches its range only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
-    ap.add_argument("--walk-streams", type=int, default=3, help="HIP streams the ten walk launches of a step are spread over")
-    ap.add_argument("--region-streams", type=int, default=1, help="HIP streams the region launches alternate between (the tail of one launch overlaps the start of the next)")
-    ap.add_argument("--region-priority", type=int, default=0, help="stream priority of the region streams (-1 = high)")
-    ap.add_argument("--region-launches", default="3",
-                    help="region pre-pass launches per step: 'per-example' (10), 'one', explicit group sizes 'a,b,c', or a number g: the examples, laid out in the batch "
-                         "costliest walk first, are scanned in g launches of consecutive examples; the walks of a group start when "
-                         "their group is scanned and run beside the next group's scan")
-    ap.add_argument("--walk-waves", type=int, default=0, help="development: cap the walk kernels at this many waves per CU (MFA_WALK_WAVES_PER_CU)")
-    ap.add_argument("--exp", default="", help="development: 'region-only' skips the walk launches")
+    ap.add_argument("--engine", choices=["auto", "table", "jit"], default="auto",
+                    help="walk kernels behind mfa_match_mixed: the table-driven walk (one launch per group of strings, any automaton per lane) or the "
+                         "kernels generated per automaton (one launch per example); auto = the library's choice (MFA_WALK)")
+    ap.add_argument("--cuts", default="", help="development: MFA_MIXED_CUTS, the fractions of the batch at which the region pre-pass is cut into groups")
     ap.add_argument("--order", default="", help="comma-separated order of the examples' segments in the batch (default: costliest walk first)")
     args = ap.parse_args()
 
@@ -393,8 +489,10 @@ def main():
     import torch
     from mfa_amd import capi, corpus, sharding
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    if args.walk_waves > 0:
-        os.environ["MFA_WALK_WAVES_PER_CU"] = str(args.walk_waves)
+    if args.engine != "auto":
+        os.environ["MFA_WALK"] = args.engine
+    if args.cuts:
+        os.environ["MFA_MIXED_CUTS"] = args.cuts
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -419,129 +517,84 @@ def main():
     comm_dev = torch.device("cpu") if rehearse else device
 
     # ---- this rank's shard: ONE mixed batch, resident in HBM ------------------------------------------
-    shards = {}
-    n_per = args.strings_per_example
-    parts_b, parts_o, pos_s, pos_b = [], [], 0, 0
     # segment order in the batch: costliest walk first (measured once on MI355X; any order is correct)
     layout = [int(x) for x in args.order.split(",")] if args.order else [2, 5, 3, 8, 9, 10, 6, 4, 1, 7]
     assert sorted(layout) == sorted(corpus.EXAMPLES)
+    n_per = args.strings_per_example
+    # what this rank holds of every example: (first string of the example's stream, count)
+    if args.scaling == "weak" or world == 1:
+        own = {ex: (0, n_per) for ex in layout}
+        seed_of = lambda ex: 0x5EED0004 + 1000 * rank + ex
+        cuts = None
+    else:
+        # strong scaling: the job's ONE batch (every example's n_per strings, seeds of rank 0) cut into `world` ranges of about equal
+        # bytes; every rank derives the same cut points from the lengths alone (no data is generated for them) and generates its
+        # own range only
+        lens_all = np.concatenate([corpus.layout(ex, corpus.pump_sizes(n_per, 0x5EED0004 + ex, args.min_len, args.max_len), (np.arange(n_per) % 2) == 0)["lens"]
+                                   for ex in layout])
+        off_job = np.zeros(len(lens_all) + 1, dtype=np.int64)
+        np.cumsum(lens_all, out=off_job[1:])
+        cuts = sharding.partition_by_bytes(off_job, world)
+        lo, hi = int(cuts[rank]), int(cuts[rank + 1])
+        own = {}
+        for k, ex in enumerate(layout):
+            a, b = max(lo, k * n_per), min(hi, (k + 1) * n_per)
+            own[ex] = (a - k * n_per, max(0, b - a))
+        seed_of = lambda ex: 0x5EED0004 + ex
+        del lens_all, off_job
+    shards = {}
+    parts_b, parts_o, pos_s, pos_b = [], [], 0, 0
+    rng_par = np.random.Generator(np.random.Philox(0x5EED0009 + rank))
     for ex in layout:
-        seed = 0x5EED0004 + 1000 * rank + ex
-        sizes = corpus.pump_sizes(n_per, seed, args.min_len, args.max_len)
-        with_suffix = (np.arange(n_per) % 2) == 0
-        d_bytes, d_off = corpus.device_batch(ex, sizes, with_suffix, device)
-        nbytes = int(d_off[-1].item())
+        first, count = own[ex]
+        sizes = corpus.pump_sizes(n_per, seed_of(ex), args.min_len, args.max_len)[first:first + count]
+        with_suffix = ((np.arange(n_per) % 2) == 0)[first:first + count]
         blob = load_blob("ex%d_plain" % ex)
         img = capi.Image(blob)
         img.prepare(local)
-        parts_b.append(d_bytes[:nbytes])
-        parts_o.append(d_off[:-1] + pos_b)
-        shards[ex] = {"img": img, "n": n_per, "nbytes": nbytes, "blob": blob, "first": pos_s,
-                      "sample": corpus.host_strings(ex, sizes[:PARITY_N], with_suffix[:PARITY_N]) if rank == 0 else []}
-        pos_s += n_per
+        nbytes = 0
+        if count:
+            d_bytes, d_off = corpus.device_batch(ex, sizes, with_suffix, device)
+            nbytes = int(d_off[-1].item())
+            parts_b.append(d_bytes[:nbytes])
+            parts_o.append(d_off[:-1] + pos_b)
+            del d_bytes, d_off
+        # the parity sample of this example: a seeded 1 % of its strings, whatever their length
+        n_par = max(1, int(round(count * PARITY_FRACTION))) if count else 0
+        par_idx = np.sort(rng_par.choice(count, size=n_par, replace=False)) if n_par else np.zeros(0, dtype=np.int64)
+        shards[ex] = {"img": img, "n": count, "nbytes": nbytes, "blob": blob, "first": pos_s, "par_idx": par_idx,
+                      "par_strings": corpus.host_strings(ex, sizes[par_idx], with_suffix[par_idx]) if rank == 0 else [],
+                      "sample": corpus.host_strings(ex, sizes[:BASELINE_N], with_suffix[:BASELINE_N]) if rank == 0 else []}
+        pos_s += count
         pos_b += nbytes
-        del d_bytes, d_off
     total_strings, total_bytes = pos_s, pos_b
     bytes_all = torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=device)])
     off_all = torch.cat(parts_o + [torch.tensor([total_bytes], dtype=torch.int64, device=device)])
     del parts_b, parts_o
     torch.cuda.empty_cache()
-    table = torch.empty((total_strings, capi.REGION_WORDS), dtype=torch.int64, device=device)
-    results = torch.zeros(total_strings, dtype=torch.uint8, device=device)
+    results = torch.zeros(max(total_strings, 1), dtype=torch.uint8, device=device)[:total_strings]
+    seg = [shards[ex]["first"] for ex in layout] + [total_strings]
+    mixed = capi.Mixed([shards[ex]["img"] for ex in layout])
 
-    main_s = torch.cuda.current_stream(device)
-    region_pool = [torch.cuda.Stream(device, priority=args.region_priority) for _ in range(max(1, args.region_streams))]
-    region_s = region_pool[0]
-    walk_pool = [torch.cuda.Stream(device) for _ in range(max(1, args.walk_streams))]
-    ev_fork = torch.cuda.Event(enable_timing=True)
-    ev_join = torch.cuda.Event(enable_timing=True)
-    ev_done = {ex: torch.cuda.Event() for ex in shards}
-
-    def seg(ex):
-        a = shards[ex]["first"]
-        return a, a + shards[ex]["n"]
-
-    if "," in args.region_launches:
-        # explicit group sizes (examples per launch, in layout order)
-        sizes_g = [int(t) for t in args.region_launches.split(",")]
-        assert sum(sizes_g) == len(layout) and min(sizes_g) > 0, "--region-launches a,b,c: group sizes must add up to the number of examples"
-        groups, at = [], 0
-        for g_n in sizes_g:
-            groups.append(layout[at:at + g_n]); at += g_n
-    else:
-        n_groups = {"per-example": len(layout), "one": 1}.get(args.region_launches) or max(1, min(len(layout), int(args.region_launches)))
-        # groups of consecutive examples with about equal bytes
-        groups, acc, cur = [], 0, []
-        for ex in layout:
-            cur.append(ex)
-            acc += shards[ex]["nbytes"]
-            if acc >= total_bytes * (len(groups) + 1) / n_groups - 1 and len(groups) < n_groups - 1:
-                groups.append(cur); cur = []
-        if cur:
-            groups.append(cur)
-    ev_g0 = [torch.cuda.Event(enable_timing=True) for _ in groups]
-    ev_g1 = [torch.cuda.Event(enable_timing=True) for _ in groups]
-
-    def launch_all(where):
-        """one pass over the mixed batch: the region pre-pass group by group on the region stream(s), each example's walk on its
-        stream as soon as its group's regions are known"""
-        ev_fork.record(main_s)
-        for rs in region_pool:
-            rs.wait_event(ev_fork)
-        for k, grp in enumerate(groups):
-            rs = region_pool[k % len(region_pool)]
-            a, b = seg(grp[0])[0], seg(grp[-1])[1]
-            ev_g0[k].record(rs)
-            capi.region_scan(bytes_all, off_all[a:b + 1], table[a:b], stream=rs)
-            ev_g1[k].record(rs)
-            for ex in grp:
-                a, b = seg(ex)
-                st = where[ex]
-                st.wait_event(ev_g1[k])
-                if args.exp != "region-only" or not walked[0]:
-                    shards[ex]["img"].match_tensors_regions(bytes_all, off_all[a:b + 1], table[a:b], results[a:b], stream=st)
-                ev_done[ex].record(st)
-        for ex in layout:
-            main_s.wait_event(ev_done[ex])
-        ev_join.record(main_s)
-
-    # set-up (untimed): one pass with every walk on one stream measures each example's walk time; the walks are then spread
-    # over the walk streams
-    where = {ex: walk_pool[0] for ex in shards}
-    walked = [False]
-    launch_all(where)
-    torch.cuda.synchronize()
-    walked[0] = True
-    cost = {ex: shards[ex]["img"].last_kernel_ms(local) for ex in shards}
-    # list scheduling with release times: a group's walks may start when its region launch has ended (estimated from this pass's
-    # region launches); each walk goes to the stream that can start it first.  Inside a step a walk takes about 1.5 x its time alone.
-    ready, t_acc = [], 0.0
-    for k in range(len(groups)):
-        t_acc += ev_g0[k].elapsed_time(ev_g1[k])
-        ready.append(t_acc)
-    free_at = [0.0] * len(walk_pool)
-    for g_k, grp in enumerate(groups):
-        for ex in grp:
-            k = min(range(len(walk_pool)), key=lambda j: max(free_at[j], ready[g_k]))
-            free_at[k] = max(free_at[k], ready[g_k]) + 1.5 * cost[ex]
-            where[ex] = walk_pool[k]
-    order = layout
-
-    kernel_ms = {ex: [] for ex in shards}
     span_ms, region_all_ms = [], []
-    counts = [total_strings] * world
+    counts_t = torch.tensor([total_strings], dtype=torch.int64, device=comm_dev)
+    if dist:
+        cl = [torch.zeros(1, dtype=torch.int64, device=comm_dev) for _ in range(world)]
+        dist.all_gather(cl, counts_t)
+        counts = [int(c.item()) for c in cl]
+    else:
+        counts = [total_strings]
 
     def step(record):
-        launch_all(where)
+        """one pass of the hot path: one library call for the whole mixed batch, then the result bitmap goes to rank 0"""
+        mixed.match_tensors(bytes_all, off_all, seg, results)
         full = sharding.gather_results(results, counts, dist, rank, world, comm_device=comm_dev) if dist else None
         if dist is None:
             full = sharding.pack_bitmap(results)                 # the bitmap a gather would send
         if record:
-            ev_join.synchronize()
-            span_ms.append(ev_fork.elapsed_time(ev_join))
-            for ex, sh in shards.items():
-                kernel_ms[ex].append(sh["img"].last_kernel_ms(local))
-            region_all_ms.append(sum(ev_g0[k].elapsed_time(ev_g1[k]) for k in range(len(groups))))
+            r_ms, sp_ms = mixed.last_ms(local)                   # HIP events on the library's own streams
+            span_ms.append(sp_ms)
+            region_all_ms.append(r_ms)
         return full
 
     def fence():
@@ -572,21 +625,23 @@ def main():
         job_bytes = sum(bytes_by_rank)
         value = job_bytes * args.steps / dt / 1e9
         if dist:                                              # rank 0 holds every rank's answers, in rank order
-            assert gathered is not None and gathered.numel() == total_strings * world
+            assert gathered is not None and gathered.numel() == sum(counts)
             assert torch.equal(gathered[:total_strings].to(results.device), (results == 1).to(torch.uint8))
         # roofline: algorithmic bytes of a step (1 B per input character + 8 B offset + 1 B result per string) over the device time
-        # of the step's kernels = the span from the fork event (before the first region launch) to the join event (after the last
-        # walk), HIP events on the streams the kernels run on
+        # of the step's kernels = from the first region launch to the end of the last walk, HIP events on the streams the library
+        # launches them on (mfa_mixed_last_ms)
         alg = total_bytes + 9 * total_strings
         kern_s = float(np.mean(span_ms)) * 1e-3
         achieved = alg / kern_s / 1e9
         reg_total_ms = float(np.mean(region_all_ms))
-        walk_total_ms = float(sum(np.mean(kernel_ms[ex]) for ex in shards))
+        engine = {capi.KERNEL_WALK: "walk_kernel (table-driven, one launch per group of strings and cell count)",
+                  capi.KERNEL_SPECIALISED: "mfa_jit_kernel (one launch per example)"}.get(shards[layout[0]]["img"].info()["last_kernel"], "?")
+        if os.environ.get("MFA_WALK", "") != "jit":
+            engine = "walk_kernel (table-driven, one launch per group of strings and cell count)"
         per_ex = {}
         for ex, sh in shards.items():
-            a, b = seg(ex)
-            per_ex[str(ex)] = {"bytes": sh["nbytes"], "walk_ms": float(np.mean(kernel_ms[ex])),
-                               "accepted": int((results[a:b] == 1).sum().item())}
+            a = sh["first"]
+            per_ex[str(ex)] = {"bytes": sh["nbytes"], "strings": sh["n"], "accepted": int((results[a:a + sh["n"]] == 1).sum().item())}
         traffic = None
         try:
             with open(TRAFFIC_FILE) as f:
@@ -596,38 +651,52 @@ def main():
                 traffic = tj["hbm_bytes_per_step"]
         except (OSError, KeyError, ValueError):
             pass
+        n_groups = len((os.environ.get("MFA_MIXED_CUTS") or "0.3,0.6,0.8,0.9").split(",")) + 1
         out = {
             "metric": "input GB/s (chars matched/sec) on 10-example attack corpus",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "ranks_seen": dist.get_world_size() if dist else 1, "backend": (dist.get_backend() if dist else None),
-            "bytes_by_rank": bytes_by_rank,
-            "config": {"workload": "10 README MFA examples (plain mode) as ONE mixed batch, %d pumped attack strings per example per GPU, "
-                                   "pump size log-uniform [%d, %d], alternating with/without suffix "
-                                   "(BASELINE configs[3] shard: 10M strings over 8 GPUs)" % (n_per, args.min_len, args.max_len),
+            "bytes_by_rank": bytes_by_rank, "strings_by_rank": counts,
+            "config": {"workload": "10 README MFA examples (plain mode) as ONE mixed batch matched by one mfa_match_mixed call per step, %d pumped attack strings per "
+                                   "example%s, pump size log-uniform [%d, %d], alternating with/without suffix "
+                                   "(BASELINE configs[3]: 10M strings over 8 GPUs)" % (
+                                       n_per, " per GPU" if args.scaling == "weak" or world == 1 else " in the whole job, cut into %d ranges of equal bytes" % world,
+                                       args.min_len, args.max_len),
                        "strings_per_example": n_per, "min_len": args.min_len, "max_len": args.max_len, "strings_per_gpu": total_strings,
                        "bytes_per_gpu": total_bytes, "parallelism": "dp%d" % world,
                        "exchange": "gather of the result bitmap to rank 0" + (" (%s)" % dist.get_backend() if dist else " (single rank: none)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "region_scan_kernel (%s) + mfa_jit_kernel (10 launches on %d streams, costliest first); duration = fork-to-join span of a step" % (
-                             "%d launch(es) over groups of consecutive examples %s" % (len(groups), groups), len(walk_pool)),
+                         "kernel": "region_scan_kernel (%d launches over groups of strings, on one stream) + %s; duration = first region launch to end of the last walk" % (
+                             n_groups, engine),
                          "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s,
-                         # the kernel that reads the bytes: its own launches, timed with HIP events on its stream
-                         "region_scan_kernel": {"launches_per_step": len(groups), "ms_per_step": reg_total_ms,
-                                                "ms_per_launch": reg_total_ms / len(groups),
+                         # the kernel that reads the bytes: its own launches, back to back on their stream, timed with HIP events
+                         "region_scan_kernel": {"launches_per_step": n_groups, "ms_per_step": reg_total_ms,
+                                                "ms_per_launch": reg_total_ms / n_groups,
                                                 "achieved": total_bytes / (reg_total_ms * 1e-3) / 1e9, "frac": total_bytes / (reg_total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                                "note": "runs beside the walk kernels of earlier examples"},
-                         "mfa_jit_kernel": {"launches_per_step": len(shards), "ms_sum_per_step": walk_total_ms,
-                                            "dispatch_ms_mean": walk_total_ms / len(shards)}},
-            "order": order, "per_example": per_ex,
+                                                "note": "runs beside the walk kernels of earlier groups"}},
+            "order": layout, "per_example": per_ex,
         }
+        if world == 1 or args.scaling == "weak":
+            # parity at scale: a seeded 1 % of every example's strings, no length cap, against the CPU restatement
+            jobs = []
+            for ex in layout:
+                sh = shards[ex]
+                if len(sh["par_idx"]):
+                    got = results[sh["first"] + torch.from_numpy(sh["par_idx"]).to(results.device)].cpu().numpy()
+                    jobs.append((sh["blob"], sh["par_strings"], got))
+            out["parity_sample"] = parity_sample(jobs)
         if not args.no_cpu_baseline and world == 1:
-            gpu_res = {ex: results[sh["first"]:sh["first"] + PARITY_N].cpu().numpy() for ex, sh in shards.items()}
+            gpu_res = {ex: results[sh["first"]:sh["first"] + BASELINE_N].cpu().numpy() for ex, sh in shards.items()}
             out["cpu_baseline"] = cpu_baseline(corpus, shards, gpu_res)
+            if out["cpu_baseline"] is not None and out.get("parity_sample"):
+                out["cpu_baseline"]["parity_restatement"] = {k: out["parity_sample"][k] for k in ("strings", "bytes", "max_len", "mismatches")}
+                out["cpu_baseline"]["parity"] = bool(out["cpu_baseline"]["parity"]) and out["parity_sample"]["mismatches"] == 0
         if not args.no_secondary and world == 1:
-            del bytes_all, off_all, table
+            mixed.close()
+            del bytes_all, off_all
             torch.cuda.empty_cache()
             sec = [secondary_dfa(device, capi), secondary_config3(device, capi), secondary_64k_all_examples(device, capi, corpus)]
             sec += secondary_no_regions(device, capi, corpus)

@@ -42,11 +42,10 @@ extern "C" {
 #define MFA_ERR_HIP           -5  /* a HIP runtime call failed; mfa_last_hip_error() has the code       */
 #define MFA_ERR_NOMEM         -6
 #define MFA_ERR_TOO_LONG      -7  /* a string is longer than MFA_MAX_STRING_BYTES                       */
-#define MFA_ERR_JIT           -8  /* compiling a specialised kernel failed (the generic kernel still works) */
+#define MFA_ERR_JIT           -8  /* compiling a specialised kernel failed (the table-driven walk still works) */
 
 /* limits of the device kernels (violations -> MFA_ERR_UNSUPPORTED at image creation) */
-#define MFA_MAX_NODES        128u      /* MFA kind: nodes                                  */
-#define MFA_MAX_DEGREE       31u       /* MFA kind: out-edges per node                     */
+#define MFA_MAX_NODES        1024u     /* MFA kind: nodes (any out-degree)                 */
 #define MFA_MAX_KERNEL_CELLS 9u        /* MFA kind: distinct memory cells ("1".."9", mfa.cpp:148) */
 #define MFA_MAX_DFA_STATES   4096u     /* NFA kind: reachable state sets after tabulation  */
 #define MFA_MAX_STRING_BYTES 0x00ffffffu /* 16 MiB - 1 per string                          */
@@ -63,10 +62,9 @@ typedef struct mfa_image_info {
 } mfa_image_info;
 
 #define MFA_KERNEL_NONE        0u
-#define MFA_KERNEL_GENERIC     1u /* mfa_walk_kernel: table-driven memory-automaton walk, slots in LDS  */
-#define MFA_KERNEL_SPECIALISED 2u /* mfa_jit_kernel: the same walk generated for one automaton, slots in VGPRs */
+#define MFA_KERNEL_WALK        1u /* walk_kernel: table-driven memory-automaton walk over a list of live states (any automaton, no compiler) */
+#define MFA_KERNEL_SPECIALISED 2u /* mfa_jit_kernel: the walk generated for one automaton, one slot per node in VGPRs */
 #define MFA_KERNEL_TABLE       3u /* dfa_walk_kernel: tabulated memory-less automaton                    */
-#define MFA_KERNEL_WALK        4u /* walk_kernel: table-driven memory-automaton walk over a list of live states */
 
 /* Build an image from a blob (include/mfa_image_format.h).  Host-only work: parse,
  * check the structural invariants the kernels rely on, and for MFA_KIND_NFA tabulate
@@ -80,12 +78,15 @@ int  mfa_image_get_info(const mfa_image_t* img, mfa_image_info* out);
  * (otherwise done by the first match call on that device). */
 int  mfa_image_prepare(mfa_image_t* img, int device);
 
-/* Memory automata whose per-string state fits the register file get a kernel specialised to the
- * automaton (straight-line code, no table loads): generated as HIP source, compiled for gfx950 with
- * hipcc and cached as a code object next to the library (or in $MFA_JIT_CACHE).  This call does
- * the generation and compilation now; it is host-only work and needs no GPU, so caches can be built
- * ahead of time.  MFA_ERR_UNSUPPORTED: the automaton is too large (the generic kernel is used);
- * MFA_ERR_JIT: the compiler failed.  Setting MFA_JIT=0 disables specialised kernels. */
+/* Every memory automaton is walked by the table-driven kernel (MFA_KERNEL_WALK) as soon as its image
+ * exists: nothing is compiled per automaton.  A small automaton (up to 128 nodes) can ALSO be given a
+ * kernel specialised to it (straight-line code, its state in registers: faster per input character on
+ * text without periodic stretches): generated as HIP source, compiled for gfx950 with hipcc and cached
+ * as a code object next to the library (or in $MFA_JIT_CACHE).  This call does that now; it is host-only
+ * work and needs no GPU, so caches can be built ahead of time.  A match call uses the specialised kernel
+ * when its code object is in the cache and never waits for a compiler (MFA_WALK=table / MFA_WALK=jit force
+ * one kernel or the other; MFA_JIT=0 disables specialised kernels).  MFA_ERR_UNSUPPORTED: the automaton
+ * is too large for a specialised kernel; MFA_ERR_JIT: the compiler failed. */
 int  mfa_image_specialize(mfa_image_t* img);
 
 /* Match n strings; string k is bytes[offsets[k] .. offsets[k+1]).  ALL pointers are

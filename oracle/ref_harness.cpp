@@ -238,15 +238,15 @@ static std::vector<std::string> read_lines() {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 3) { fprintf(stderr, "usage: ref_harness dump|match|time <mode> <regex> | front <regex>\n"); return 2; }
+    if (argc < 3) { fprintf(stderr, "usage: ref_harness dump|match|time <mode> <regex> | front|frontlog <regex>\n"); return 2; }
     std::string cmd = argv[1];
-    if (cmd == "front") {
-        // body of the BNF/Reverse REPL, main.cpp:55-66
+    if (cmd == "front" || cmd == "frontlog") {
+        // body of the BNF/Reverse REPL, main.cpp:55-66; frontlog: with -log (the rewrite trace goes to log.txt in the working directory)
         std::string regex = argv[2];
         g_in_ref = true;
         Regexp* re = Regexp::parse_regexp(regex);
         re->is_backref_correct();
-        Regexp* b = re->bnf(false);
+        Regexp* b = re->bnf(cmd == "frontlog");
         if (!b->is_bad_bnf) {
             std::string bs = b->to_string();
             Regexp* r = b->reverse();

@@ -76,8 +76,6 @@ void device_release(DeviceState& ds) {
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) return;
     (void)hipSetDevice(ds.device);
-    if (ds.d_edge_begin) (void)hipFree(ds.d_edge_begin);
-    if (ds.d_edges) (void)hipFree(ds.d_edges);
     if (ds.d_dfa_trans) (void)hipFree(ds.d_dfa_trans);
     if (ds.d_dfa_accept) (void)hipFree(ds.d_dfa_accept);
     if (ds.d_byte_class) (void)hipFree(ds.d_byte_class);
@@ -108,9 +106,7 @@ int device_prepare(mfa_image* img, int device, DeviceState** out) {
     };
     int rc = MFA_OK;
     if (h.h.kind == MFA_KIND_MFA) {
-        rc = up((void**)&ds.d_edge_begin, h.edge_begin.data(), h.edge_begin.size() * 4);
-        if (rc == MFA_OK) rc = up((void**)&ds.d_edges, h.edges.data(), h.edges.size() * sizeof(mfa_blob_edge));
-        if (rc == MFA_OK && img->walk_ok) rc = up((void**)&ds.d_walk, img->walk.words.data(), img->walk.words.size() * 4);
+        if (img->walk_ok) rc = up((void**)&ds.d_walk, img->walk.words.data(), img->walk.words.size() * 4);
     } else {
         rc = up((void**)&ds.d_dfa_trans, h.dfa_trans.data(), h.dfa_trans.size() * 2);
         if (rc == MFA_OK) rc = up((void**)&ds.d_dfa_accept, h.dfa_accept.data(), h.dfa_accept.size());
@@ -136,7 +132,10 @@ int mfa_image_create(const void* blob, size_t n_bytes, mfa_image_t** out) {
     int rc = parse_blob(blob, n_bytes, img->host);
     if (rc == MFA_OK) rc = img->host.h.kind == MFA_KIND_MFA ? check_mfa_invariants(img->host) : tabulate_nfa(img->host);
     if (rc != MFA_OK) { delete img; return rc; }
-    if (img->host.h.kind == MFA_KIND_MFA) img->walk_ok = build_walk_tables(img->host, img->walk) == MFA_OK;
+    if (img->host.h.kind == MFA_KIND_MFA) {
+        img->walk_ok = build_walk_tables(img->host, img->walk) == MFA_OK;
+        if (!img->walk_ok && !jit_enabled(img->host)) { delete img; return MFA_ERR_UNSUPPORTED; }      // no kernel could walk it
+    }
     *out = img;
     return MFA_OK;
 }
@@ -162,7 +161,8 @@ int mfa_image_prepare(mfa_image_t* img, int device) {
     std::lock_guard<std::mutex> lk(img->mu);
     DeviceState* ds = nullptr;
     int rc = device_prepare(img, device, &ds);
-    if (rc == MFA_OK && img->host.h.kind == MFA_KIND_MFA) (void)jit_load(img->host, *ds);
+    if (rc == MFA_OK && img->host.h.kind == MFA_KIND_MFA && walk_mode() != 1 && (walk_mode() == 2 || !img->walk_ok || (jit_lanes(img->host) == 64u && jit_cached(img->host))))
+        (void)jit_load(img->host, *ds);
     return rc;
 }
 
@@ -194,8 +194,22 @@ static int match_impl(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* 
     if (rc != MFA_OK) return rc;
     HIP_TRY(hipSetDevice(device));
     const bool is_mfa = img->host.h.kind == MFA_KIND_MFA;
-    const bool table_walk = is_mfa && img->walk_ok && walk_selected();
-    const bool jit = is_mfa && !table_walk && jit_load(img->host, *ds);
+    // Which walk: the table-driven kernel (walk.hip) works for every automaton at once; a kernel generated for this automaton
+    // (jit_gen.cpp) steps faster on small automata but has to be compiled first.  Automatic: the generated kernel if its code object
+    // is in the cache already (mfa_image_specialize builds it ahead of time), is not of the "huge" kind, and MFA_JIT != 0 -- a
+    // match call never waits for a compiler.  MFA_WALK=table / MFA_WALK=jit force one or the other (jit compiles on demand).
+    const int mode = walk_mode();
+    bool want_jit = false;
+    if (is_mfa) {
+        if (mode == 2 || !img->walk_ok) want_jit = jit_enabled(img->host);
+        else if (mode == 0) {
+            if (!ds->jit_tried && !ds->jit_probed) { ds->jit_probed = true; ds->jit_in_cache = jit_lanes(img->host) == 64u && jit_cached(img->host); }
+            want_jit = ds->jit_fn != nullptr || ds->jit_in_cache;
+        }
+    }
+    const bool jit = want_jit && jit_load(img->host, *ds);
+    const bool table_walk = is_mfa && !jit && img->walk_ok;
+    if (is_mfa && !jit && !table_walk) return MFA_ERR_JIT;      // only a generated kernel could walk it, and none could be built
     LaunchCtx* cx = nullptr;
     rc = ctx_acquire(*ds, stream, &cx);
     if (rc != MFA_OK) return rc;
@@ -231,9 +245,6 @@ static int match_impl(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* 
             d_table = cx->d_regions;
         }
         rc = launch_mfa_jit(*ds, *cx, d_bytes, d_offsets, n, d_results, d_table, stream);
-    } else if (is_mfa) {
-        img->last_kernel = MFA_KERNEL_GENERIC;
-        rc = launch_mfa_walk(img->host, *ds, *cx, d_bytes, d_offsets, n, d_results, stream);
     } else {
         img->last_kernel = MFA_KERNEL_TABLE;
         rc = launch_dfa_walk(img->host, *ds, *cx, d_bytes, d_offsets, n, d_results, stream);

@@ -52,7 +52,6 @@ int check_mfa_invariants(const HostImage& img) {
     if (h.n_nodes > MFA_MAX_NODES || h.n_cells > MFA_MAX_KERNEL_CELLS) return MFA_ERR_UNSUPPORTED;
     if (img.edge_begin[h.finish + 1] != img.edge_begin[h.finish]) return MFA_ERR_UNSUPPORTED;
     for (uint32_t n = 0; n < h.n_nodes; n++) {
-        if (img.edge_begin[n + 1] - img.edge_begin[n] > MFA_MAX_DEGREE) return MFA_ERR_UNSUPPORTED;
         for (uint32_t e = img.edge_begin[n]; e < img.edge_begin[n + 1]; e++) {
             bool eps = img.edges[e].flags & MFA_EDGE_EPS;
             bool to_finish = img.edges[e].target == h.finish;

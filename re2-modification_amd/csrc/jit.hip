@@ -63,16 +63,23 @@ static std::string source_key(const std::string& src) {
     return buf;
 }
 
-bool jit_enabled(const HostImage& img) {
-    const char* e = getenv("MFA_JIT");
-    if (e && e[0] == '0') return false;
-    return img.h.kind == MFA_KIND_MFA && jit_lanes(img) != 0;      // up to 272 slot registers in VGPRs, beyond that slot sets in LDS
-}
-
 static bool file_exists(const std::string& p) {
     struct stat st;
     return stat(p.c_str(), &st) == 0 && st.st_size > 0;
 }
+
+bool jit_enabled(const HostImage& img) {
+    const char* e = getenv("MFA_JIT");
+    if (e && e[0] == '0') return false;
+    // up to 272 slot registers in VGPRs, beyond that slot sets in LDS; the generated code keeps node sets in 128-bit masks
+    return img.h.kind == MFA_KIND_MFA && img.h.n_nodes <= 128u && jit_lanes(img) != 0;
+}
+
+bool jit_cached(const HostImage& img) {
+    if (!jit_enabled(img)) return false;
+    return file_exists(cache_dir() + "/" + source_key(jit_generate_source(img)) + ".hsaco");
+}
+
 
 // generate + compile into the cache (host-only, no GPU needed); returns the code-object path or ""
 std::string jit_compile(const HostImage& img, std::string* err) {
@@ -136,13 +143,13 @@ bool jit_load(const HostImage& img, DeviceState& ds) {
     std::string err;
     std::string obj = jit_compile(img, &err);
     if (obj.empty()) {
-        if (jit_enabled(img)) fprintf(stderr, "mfa_hip: specialised kernel unavailable (%s); using the generic kernel\n", err.c_str());
+        if (jit_enabled(img)) fprintf(stderr, "mfa_hip: specialised kernel unavailable (%s); using the table-driven walk\n", err.c_str());
         return false;
     }
     hipModule_t mod = nullptr;
     hipFunction_t fn = nullptr;
     if (hipModuleLoad(&mod, obj.c_str()) != hipSuccess || hipModuleGetFunction(&fn, mod, "mfa_jit_kernel") != hipSuccess) {
-        fprintf(stderr, "mfa_hip: cannot load %s; using the generic kernel\n", obj.c_str());
+        fprintf(stderr, "mfa_hip: cannot load %s; using the table-driven walk\n", obj.c_str());
         if (mod) (void)hipModuleUnload(mod);
         return false;
     }

@@ -1,27 +1,6 @@
-// HIP kernels of the match path, written for gfx950 (MI355X): 64-wide wavefronts,
-// one input string per lane, per-string automaton state in LDS (struct-of-arrays, one
-// bank per lane), the automaton itself read through the scalar cache.
-//
-//   mfa_walk_kernel  -- MFA::match (reference mfa.cpp:215-236) for a batch of strings
-//   dfa_walk_kernel  -- Automata::match (reference automata.cpp:177-210) on the tabulated
-//                       step function (image_host.cpp: tabulate_nfa)
-//
-// ---- how the MFA kernel restates mfa.cpp ---------------------------------------------------
-// The reference keeps a std::set of (pos, node, memory) states, but each step only the first
-// state per node (in set order) is evaluated and all others are dropped (mfa.cpp:206-211).
-// So a string's live state is one SLOT per automaton node, holding the minimum state for that
-// node under the set order:
-//     (pos, name of the first memory cell, allocation order of that cell's Variable).
-// Allocation order is creation order of the state (copy_memory allocates the cells when the
-// state is created, mfa.cpp:107-114), which for states created within one step is
-//     (pos of the source state, node of the source state, DFS index of the creating edge)
-// because sources are evaluated in (pos, node) order; a state re-inserted unchanged (the
-// "wait" branch, mfa.cpp:195-197) keeps its old Variables and is therefore older than every
-// state created in the current step.  Slots carry that key as three words P, Q, R.
-// Memory cell values are always contiguous spans of the scan-order input (every write appends
-// exactly the text just consumed, mfa.cpp:89-104), so a cell is (start, len, flags).
-// `finish` is reached only through epsilon edges and only kept when pos == len
-// (mfa.cpp:138-140,143-147): it is an accept flag, and once set it stays set.
+// HIP kernels for memory-less automata, written for gfx950 (MI355X): Automata::match (reference automata.cpp:177-210) on the
+// tabulated step function (image_host.cpp: tabulate_nfa).  One input string per lane, 64 strings per wavefront.
+// (Memory automata: regions.hip + walk.hip, or the kernels jit_gen.cpp generates.)
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -40,283 +19,6 @@ namespace mfa {
         hipError_t e_ = (expr);                                         \
         if (e_ != hipSuccess) { set_last_hip_error((int)e_); return MFA_ERR_HIP; } \
     } while (0)
-
-static constexpr uint32_t kEmpty = MFA_EMPTY;
-
-template <int K>
-struct Mem {                 // the memory of one state, in registers
-    uint32_t start[K];
-    uint32_t len[K];
-    uint32_t fl[K];          // F_* | ch << 8
-};
-
-struct DevImg {
-    const uint32_t* edge_begin;
-    const uint2*    edges;
-    uint32_t n_nodes, start, finish, reversed;
-};
-
-// ---- LDS slot arrays --------------------------------------------------------------------------
-// word index of (buf, node, w) for this lane:  (((buf * N + node) * W + w) * 64 + lane
-template <int K>
-struct SlotLayout {
-    static constexpr int W = 4 + 3 * K;      // P, Q, R (low word), then per cell start, len, flags, then R's high word
-    static constexpr int RHI = 3 + 3 * K;    // R = 5 bits per level of the unset-cell recursion, K + 1 levels: 50 bits for nine cells
-};
-
-template <int K, bool LDS_SLOTS>
-struct Slots {
-    uint32_t* base;          // LDS or global scratch, already offset to this wave and lane
-    uint32_t  N;
-    __device__ __forceinline__ uint32_t* at(uint32_t buf, uint32_t node, uint32_t w) const {
-        return base + (((buf * N + node) * SlotLayout<K>::W + w) << 6);
-    }
-};
-
-template <int K>
-__device__ __forceinline__ uint32_t first_name(const Mem<K>& m) {
-#pragma unroll
-    for (int c = 0; c < K; c++)
-        if (m.fl[c] & F_PRESENT) return (uint32_t)(c + 1);
-    return 0u;
-}
-
-// ---- the walk -----------------------------------------------------------------------------------
-template <int K, bool REV, bool LDS_SLOTS>
-struct Walker {
-    DevImg   g;
-    Slots<K, LDS_SLOTS> S;
-    Input    in;
-    uint32_t curbuf;         // wave-uniform
-    uint32_t turn = 0;       // wave-uniform: iterations since the byte windows were last turned over (device_common.h)
-    // per-lane
-    bool     active;         // has a string in flight
-    bool     accept;
-    bool     any_next;       // something was inserted into the next state set this step
-    uint32_t i;              // step index (scan position)
-    uint32_t ch;             // scan[i]
-    bool     final_pass;     // i == len
-
-    __device__ __forceinline__ void load_mem(uint32_t buf, uint32_t node, Mem<K>& m) const {
-#pragma unroll
-        for (int c = 0; c < K; c++) {
-            m.start[c] = *S.at(buf, node, 3 + 3 * c);
-            m.len[c]   = *S.at(buf, node, 4 + 3 * c);
-            m.fl[c]    = *S.at(buf, node, 5 + 3 * c);
-        }
-    }
-
-    // insert (P,Q,R,m) into the next-set slot of `node` if it beats what is there
-    __device__ __forceinline__ void insert(bool pred, uint32_t node, uint32_t P, uint32_t Q, uint64_t R, const Mem<K>& m) {
-        uint32_t nb = curbuf ^ 1u;
-        uint32_t eP = *S.at(nb, node, 0), eQ = *S.at(nb, node, 1);
-        const uint64_t eR = ((uint64_t)*S.at(nb, node, SlotLayout<K>::RHI) << 32) | *S.at(nb, node, 2);
-        bool win = pred && (P < eP || (P == eP && (Q < eQ || (Q == eQ && R < eR))));
-        if (win) {
-            *S.at(nb, node, 0) = P; *S.at(nb, node, 1) = Q; *S.at(nb, node, 2) = (uint32_t)R; *S.at(nb, node, SlotLayout<K>::RHI) = (uint32_t)(R >> 32);
-#pragma unroll
-            for (int c = 0; c < K; c++) {
-                *S.at(nb, node, 3 + 3 * c) = m.start[c];
-                *S.at(nb, node, 4 + 3 * c) = m.len[c];
-                *S.at(nb, node, 5 + 3 * c) = m.fl[c];
-            }
-            any_next = true;
-        }
-    }
-
-    // MFA::doMemoryWriteActions (mfa.cpp:80-105) on a copy; the consumed text is
-    // scan[tstart, tstart+tlen), all bytes equal `tch` iff tuni
-    __device__ __forceinline__ void apply_actions(Mem<K>& m, uint32_t actions, uint32_t tstart, uint32_t tlen,
-                                                  bool tuni, uint32_t tch) const {
-#pragma unroll
-        for (int c = 0; c < K; c++) {
-            uint32_t act = (actions >> (2 * (c + 1))) & 3u;       // wave-uniform
-            uint32_t f = m.fl[c];
-            if (act == MFA_ACT_OPEN) {                            // create if absent, open(), write(t)
-                m.start[c] = tstart; m.len[c] = tlen;
-                m.fl[c] = F_PRESENT | F_OPEN | (tuni ? F_UNI : 0u) | (tch << 8);
-            } else if (act == MFA_ACT_CLOSE) {                    // close()
-                m.fl[c] = f & ~F_OPEN;
-            } else {                                              // write(t) when open
-                bool w = (f & (F_PRESENT | F_OPEN)) == (F_PRESENT | F_OPEN) && tlen != 0u;
-                bool was_empty = m.len[c] == 0u;
-                uint32_t fch = (f >> 8) & 0xffu;
-                bool uni = was_empty ? tuni : ((f & F_UNI) && tuni && fch == tch);
-                uint32_t nf = (f & (F_PRESENT | F_OPEN | F_READ)) | (uni ? F_UNI : 0u) | ((was_empty ? tch : fch) << 8);
-                if (w) {
-                    if (was_empty) m.start[c] = tstart;
-                    m.len[c] += tlen;
-                    m.fl[c] = nf;
-                }
-            }
-        }
-    }
-
-    __device__ __forceinline__ bool suffix_ok(bool pred, const Mem<K>& m) const {        // mfa.cpp:116-133
-        if (!REV) return pred;
-        uint32_t needed = 0;
-#pragma unroll
-        for (int c = 0; c < K; c++)
-            if ((m.fl[c] & F_PRESENT) && ((m.fl[c] & F_OPEN) || !(m.fl[c] & F_READ))) needed += m.len[c];
-        return pred && needed <= in.len - i;
-    }
-
-    // MFA::evaluateState (mfa.cpp:136-200) for the lanes in `live`, all of which sit on `node`
-    // with state (pos, m).  LEVEL = recursion depth through "unset cell" edges (mfa.cpp:148-160).
-    template <int LEVEL>
-    __device__ __forceinline__ void eval_node(uint32_t node, bool live, uint32_t pos, Mem<K>& m, uint32_t Q, uint64_t Rprefix) {
-        live = suffix_ok(live, m);
-        if (!__any(live)) return;
-        const bool here    = live && !final_pass && pos == i;     // may consume (mfa.cpp:161)
-        const bool waiting = live && !final_pass && pos > i;      // mfa.cpp:195
-        bool reinsert = false;
-        const uint32_t e0 = g.edge_begin[node], e1 = g.edge_begin[node + 1];
-        for (uint32_t e = e0; e < e1; e++) {
-            const uint2 ed = g.edges[e];                           // uniform -> scalar load
-            const uint32_t label = ed.x & 0xffu, eflags = (ed.x >> 8) & 0xffu, target = ed.x >> 16, actions = ed.y;
-            const uint64_t R = Rprefix | ((uint64_t)(e - e0 + 1u) << (5 * (K - LEVEL)));
-            if (eflags & MFA_EDGE_EPS) {                           // mfa.cpp:143-147 -> finish keeps it iff pos == len
-                if (live && pos == in.len) accept = true;
-                continue;
-            }
-            const bool is_digit = label >= '1' && label <= '9';
-            const int  d = is_digit ? (int)label - '1' : 0;       // 0-based cell, uniform
-            bool absent = false;
-            if (is_digit) {
-#pragma unroll
-                for (int c = 0; c < K; c++)
-                    if (c == d) absent = !(m.fl[c] & F_PRESENT);
-            }
-            const bool take_absent = live && absent;
-            if constexpr (LEVEL < K) {
-                if (__any(take_absent)) {                          // mfa.cpp:148-160: create the cell, recurse, consume nothing
-                    Mem<K> t = m;
-                    uint32_t act = (actions >> (2 * (d + 1))) & 3u;
-#pragma unroll
-                    for (int c = 0; c < K; c++)
-                        if (c == d) {
-                            t.start[c] = pos; t.len[c] = 0u;
-                            t.fl[c] = F_PRESENT | (act == MFA_ACT_OPEN ? F_OPEN : 0u) | F_UNI;
-                        }
-                    eval_node<LEVEL + 1>(target, take_absent, pos, t, Q, R);
-                }
-            }
-            const bool other = live && !absent;
-            const bool consume = other && here;
-            const bool lit = consume && (label == '.' || label == ch);             // mfa.cpp:171
-            if (__any(lit)) {
-                Mem<K> t = m;
-                apply_actions(t, actions, i, 1u, true, ch);
-                insert(lit, target, ((pos + 1u) << 4) | first_name(t), Q, R, t);
-            }
-            const bool rd = consume && !lit && is_digit;                           // mfa.cpp:176
-            if (__any(rd)) {
-                Mem<K> t = m;                                     // copy BEFORE read() marks the source (mfa.cpp:167 vs 177)
-                uint32_t vs = 0, vl = 0, vf = 0;
-#pragma unroll
-                for (int c = 0; c < K; c++)
-                    if (c == d) { vs = m.start[c]; vl = m.len[c]; vf = m.fl[c]; if (rd) m.fl[c] |= F_READ; }
-                bool ok = false;
-                if (rd) ok = read_matches<REV>(in, i, ch, vs, vl, vf);
-                if (__any(ok)) {
-                    apply_actions(t, actions, i, vl, (vf & F_UNI) != 0u, (vf >> 8) & 0xffu);
-                    insert(ok, target, ((pos + vl) << 4) | first_name(t), Q, R, t);
-                }
-            }
-            reinsert = reinsert || (other && waiting);                             // mfa.cpp:195-197
-        }
-        if (__any(reinsert)) {
-            // the state itself goes back into the set; at LEVEL 0 it is the old object (older than
-            // anything created this step: Q = R = 0), deeper it is the state the unset-cell edge made
-            insert(reinsert, node, (pos << 4) | first_name(m), LEVEL == 0 ? 0u : Q, LEVEL == 0 ? (uint64_t)0 : Rprefix, m);
-        }
-    }
-
-    __device__ __forceinline__ void clear_lane_slots() {
-        for (uint32_t n = 0; n < g.n_nodes; n++) { *S.at(0, n, 0) = kEmpty; *S.at(1, n, 0) = kEmpty; }
-    }
-
-    __device__ __forceinline__ void start_string(uint64_t base, uint32_t len) {
-        input_reset(in, base, len);
-        i = 0; accept = false; active = true;
-        clear_lane_slots();
-        *S.at(curbuf, g.start, 0) = 0u;                            // (pos 0, start, {})  mfa.cpp:217-219
-#pragma unroll
-        for (int c = 0; c < K; c++) {
-            *S.at(curbuf, g.start, 3 + 3 * c) = 0u; *S.at(curbuf, g.start, 4 + 3 * c) = 0u; *S.at(curbuf, g.start, 5 + 3 * c) = 0u;
-        }
-    }
-
-    // one evaluateStates call (mfa.cpp:203-213) for every active lane; returns per lane
-    // whether the string is finished after it
-    __device__ __forceinline__ bool step() {
-        final_pass = (i == in.len);
-        ch = 0x100u;
-        if (turn == 0u) window_turn<REV>(in, i, active && !final_pass);
-        if (active && !final_pass) ch = stream_byte<REV>(in, i, 16u - turn);
-        turn = (turn + 1u) & 15u;
-        any_next = false;
-        for (uint32_t n = 0; n < g.n_nodes; n++) {
-            uint32_t P = active ? *S.at(curbuf, n, 0) : kEmpty;
-            bool live = P != kEmpty;
-            if (!__any(live)) continue;
-            if (live) *S.at(curbuf, n, 0) = kEmpty;               // consumed: this buffer is the next step's empty set
-            uint32_t pos = P >> 4;
-            live = live && pos >= i;                               // pos < i: nothing can be inserted from a stale state
-            if (!__any(live)) continue;
-            Mem<K> m;
-            load_mem(curbuf, n, m);
-            eval_node<0>(n, live, pos, m, (pos << 8) | n, 0u);
-        }
-        bool done = false;
-        if (active) {
-            if (accept || final_pass || !any_next) done = true;    // mfa.cpp:224-225, 227-235
-            i++;
-        }
-        return done;
-    }
-};
-
-template <int K, bool REV, bool LDS_SLOTS>
-__global__ void __launch_bounds__(64)
-mfa_walk_kernel(DevImg g, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
-                uint8_t* __restrict__ results, unsigned long long* counter, uint32_t* scratch) {
-    extern __shared__ uint32_t lds[];
-    const uint32_t lane = threadIdx.x & 63u;
-    Walker<K, REV, LDS_SLOTS> w;
-    w.g = g;
-    w.S.N = g.n_nodes;
-    if (LDS_SLOTS) w.S.base = lds + lane;
-    else w.S.base = scratch + (size_t)blockIdx.x * (2u * g.n_nodes * SlotLayout<K>::W * 64u) + lane;
-    w.in.bytes = bytes;
-    w.in.total16 = (offsets[n] + 15u) & ~(uint64_t)15;
-    input_reset(w.in, 0, 0);
-    w.curbuf = 0;
-    w.active = false; w.accept = false; w.i = 0;
-    uint64_t sid = 0;
-    bool exhausted = false;
-    for (;;) {
-        // hand a new string to every idle lane
-        if (!w.active && !exhausted) {
-            for (;;) {
-                sid = atomicAdd(counter, 1ull);
-                if (sid >= n) { exhausted = true; break; }
-                uint64_t b = offsets[sid], e = offsets[sid + 1];
-                uint64_t len = e - b;
-                if (len > MFA_MAX_STRING_BYTES) { results[sid] = 2; continue; }    // flagged; the launcher reports it
-                w.start_string(b, (uint32_t)len);
-                break;
-            }
-        }
-        if (!__any(w.active)) break;
-        bool done = w.step();
-        if (done) {
-            results[sid] = w.accept ? 1 : 0;
-            w.active = false;
-        }
-        w.curbuf ^= 1u;
-    }
-}
 
 // ---- table walk for memory-less automata -------------------------------------------------------
 // One string per lane.  LDS holds one fused table: next[state][byte] (16-bit entries, the state
@@ -551,65 +253,6 @@ dfa_big_kernel(const uint16_t* __restrict__ trans, const uint8_t* __restrict__ a
 }
 
 // ---- launchers ------------------------------------------------------------------------------------
-template <int K, bool REV>
-static int launch_mfa_k(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
-                        uint64_t n, uint8_t* d_results, hipStream_t stream) {
-    DevImg g{ds.d_edge_begin, ds.d_edges, img.h.n_nodes, img.h.start, img.h.finish, img.h.is_reversed};
-    const size_t per_wave = (size_t)2 * img.h.n_nodes * SlotLayout<K>::W * 64 * sizeof(uint32_t);
-    const bool lds_slots = per_wave <= 40 * 1024;             // >= 4 waves per CU out of 160 KiB
-    HIP_TRY(hipMemsetAsync(cx.d_counter, 0, sizeof(unsigned long long), stream));
-    int waves_per_cu = 8;
-    if (lds_slots) {
-        int by_lds = (int)((160 * 1024) / per_wave);
-        if (by_lds < waves_per_cu) waves_per_cu = by_lds;
-    }
-    uint64_t want = (n + 63) / 64;
-    uint64_t grid = (uint64_t)ds.n_cus * waves_per_cu;
-    if (grid > want) grid = want;
-    if (grid == 0) grid = 1;
-    if (!lds_slots) {
-        int rc = ctx_reserve((void**)&cx.d_scratch, &cx.scratch_bytes, (size_t)grid * per_wave);
-        if (rc != MFA_OK) return rc;
-    }
-    HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_start, stream));
-    if (lds_slots) {
-        auto kern = mfa_walk_kernel<K, REV, true>;
-        HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)per_wave));
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), per_wave, stream, g, d_bytes, d_offsets, n, d_results,
-                           cx.d_counter, (uint32_t*)nullptr);
-    } else {
-        hipLaunchKernelGGL((mfa_walk_kernel<K, REV, false>), dim3((unsigned)grid), dim3(64), 0, stream, g, d_bytes,
-                           d_offsets, n, d_results, cx.d_counter, cx.d_scratch);
-    }
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_stop, stream));
-    return MFA_OK;
-}
-
-template <int K>
-static int launch_mfa_rev(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* b, const uint64_t* o, uint64_t n,
-                          uint8_t* r, hipStream_t s) {
-    return img.h.is_reversed ? launch_mfa_k<K, true>(img, ds, cx, b, o, n, r, s) : launch_mfa_k<K, false>(img, ds, cx, b, o, n, r, s);
-}
-
-int launch_mfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
-                    uint64_t n, uint8_t* d_results, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
-    switch (img.h.n_cells) {
-        case 0:
-        case 1: return launch_mfa_rev<1>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-        case 2: return launch_mfa_rev<2>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-        case 3: return launch_mfa_rev<3>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-        case 4: return launch_mfa_rev<4>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-        case 5: return launch_mfa_rev<5>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-        case 6: return launch_mfa_rev<6>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-        case 7: return launch_mfa_rev<7>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-        case 8: return launch_mfa_rev<8>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-        case 9: return launch_mfa_rev<9>(img, ds, cx, d_bytes, d_offsets, n, d_results, s);
-    }
-    return MFA_ERR_UNSUPPORTED;
-}
-
 static bool make_packed(const HostImage& img, DfaPacked& pk) {
     if (img.dfa_states > 8 || img.n_classes > 8 || img.n_classes < 1) return false;
     std::memset(&pk, 0, sizeof pk);

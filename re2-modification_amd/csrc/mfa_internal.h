@@ -60,9 +60,6 @@ struct LaunchCtx {
 
 struct DeviceState {
     int       device = -1;
-    // MFA kind
-    uint32_t* d_edge_begin = nullptr;
-    uint2*    d_edges      = nullptr;   // mfa_blob_edge reinterpreted as two dwords
     // NFA kind
     uint16_t* d_dfa_trans  = nullptr;
     uint8_t*  d_dfa_accept = nullptr;
@@ -73,6 +70,7 @@ struct DeviceState {
     int                 n_cus = 0;
     // specialised kernel (jit.hip), if one is loaded for this device
     bool                jit_tried = false;
+    bool                jit_probed = false, jit_in_cache = false;      // automatic mode: looked whether the code object is cached
     void*               jit_mod = nullptr;     // hipModule_t
     void*               jit_fn  = nullptr;     // hipFunction_t
     int                 jit_waves_per_cu = 0;
@@ -96,8 +94,6 @@ struct mfa_image {
 namespace mfa {
 
 // launchers (kernels.hip); all asynchronous on `stream`
-int launch_mfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
-                    uint64_t n, uint8_t* d_results, void* stream);
 int launch_dfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream);
 // regions.hip
@@ -111,6 +107,7 @@ uint32_t    jit_slot_registers(const HostImage& img);
 uint32_t    jit_lanes(const HostImage& img);
 std::string jit_generate_source(const HostImage& img);
 bool        jit_enabled(const HostImage& img);
+bool        jit_cached(const HostImage& img);      // its code object is in the cache already
 std::string jit_compile(const HostImage& img, std::string* err);
 bool        jit_load(const HostImage& img, DeviceState& ds);
 void        jit_unload(DeviceState& ds);
@@ -123,7 +120,7 @@ struct WalkPlanInput { uint32_t K, max_live; bool reversed; uint32_t table_words
 int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                 uint8_t* d_results, const uint64_t* d_regions, uint32_t n_seg, const uint32_t* seg_first, const uint32_t* seg_table,
                 uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream);
-bool walk_selected();      // MFA_WALK=table|jit
+int  walk_mode();          // MFA_WALK: 0 auto (default), 1 table, 2 jit
 void set_last_hip_error(int e);
 
 }  // namespace mfa

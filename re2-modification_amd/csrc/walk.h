@@ -32,6 +32,7 @@ struct WalkLaunch {
     WalkArgs args;
     unsigned grid;                    // workgroups of 256 threads
     bool     reversed;
+    bool     tables_global;           // the tables do not fit LDS: the kernel reads them from global memory (shared_words = 0)
 };
 
 #define MFA_WALK_DECL(K) int launch_walk_k##K(const WalkLaunch& L, void* stream); size_t walk_wave_words_k##K(uint32_t C);

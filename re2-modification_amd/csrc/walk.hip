@@ -44,14 +44,16 @@ struct TicketFeeder {
 };
 
 // LDS of a workgroup: [tables] then per wave [lv][ld][sb][sa][rt_cache]
-template <int K, bool REV, bool STATS>
+// TG: the tables stay in global memory (automata whose tables do not fit LDS beside the lists)
+template <int K, bool REV, bool STATS, bool TG>
 __global__ void __launch_bounds__(256, WALK_MIN_WAVES)
 walk_kernel(WalkArgs a) {
     extern __shared__ uint32_t smem[];
     const uint32_t wave = threadIdx.x >> 6;
-    for (uint32_t k = threadIdx.x; k < a.table_words; k += blockDim.x) smem[k] = a.tables[k];
-    const TablePtr T = (TablePtr)smem;
-    __syncthreads();
+    if (!TG) {
+        for (uint32_t k = threadIdx.x; k < a.table_words; k += blockDim.x) smem[k] = a.tables[k];
+        __syncthreads();
+    }
     constexpr uint32_t W = Lay<K>::W, DW = Lay<K>::DW;
     const uint32_t per_wave = a.C * 64u * (3u * W + 3u * DW) + 2u * 64u * MFA_RT_CACHED;
     // the wave's number as a scalar: everything derived from it stays in scalar registers
@@ -75,7 +77,8 @@ walk_kernel(WalkArgs a) {
 #if WALK_STATS
     // development build: per-lane counts and per-wave cycle counts, added up in a.counter[8 ..]
     WaveStats ws;
-    walk_wave<K, REV, TicketFeeder>(b, T, st, rtc, feed, &ws);
+    if (TG) walk_wave<K, REV, TicketFeeder, TablePtrG>(b, a.tables, st, rtc, feed, &ws);
+    else walk_wave<K, REV, TicketFeeder, TablePtr>(b, (TablePtr)smem, st, rtc, feed, &ws);
     unsigned long long* out = a.counter + 8;
     const unsigned long long lanev[7] = {ws.dual * 0ull + ws.skipped, ws.probes, ws.hits, ws.steps, ws.spills, ws.strings, 0ull};
     for (int k = 0; k < 6; k++) atomicAdd(&out[k], lanev[k]);
@@ -85,7 +88,8 @@ walk_kernel(WalkArgs a) {
         atomicAdd(&out[17], 1ull);
     }
 #else
-    walk_wave<K, REV, TicketFeeder>(b, T, st, rtc, feed, nullptr);
+    if (TG) walk_wave<K, REV, TicketFeeder, TablePtrG>(b, a.tables, st, rtc, feed, nullptr);
+    else walk_wave<K, REV, TicketFeeder, TablePtr>(b, (TablePtr)smem, st, rtc, feed, nullptr);
 #endif
 }
 
@@ -104,14 +108,15 @@ int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = ((size_t)a.shared_words + 4u * wave_words(a.C)) * 4u;
     if (lds > 160u * 1024u) return MFA_ERR_UNSUPPORTED;
-    hipError_t e;
-    if (L.reversed) {
-        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, true, WALK_STATS != 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, true, WALK_STATS != 0>), dim3(L.grid), dim3(256), lds, s, a);
-    } else {
-        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, false, WALK_STATS != 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, false, WALK_STATS != 0>), dim3(L.grid), dim3(256), lds, s, a);
-    }
+    hipError_t e = hipSuccess;
+#define WALK_GO(REVV, TGV)                                                                                                                   \
+    do {                                                                                                                                     \
+        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, REVV, WALK_STATS != 0, TGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, REVV, WALK_STATS != 0, TGV>), dim3(L.grid), dim3(256), lds, s, a);          \
+    } while (0)
+    if (L.tables_global) { if (L.reversed) WALK_GO(true, true); else WALK_GO(false, true); }
+    else { if (L.reversed) WALK_GO(true, false); else WALK_GO(false, false); }
+#undef WALK_GO
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
     return MFA_OK;

@@ -98,7 +98,8 @@ WALK_DEV bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, u
 #else
 #define WALK_LDS __attribute__((address_space(3)))
 #endif
-typedef const WALK_LDS uint32_t* TablePtr;
+typedef const WALK_LDS uint32_t* TablePtr;      // tables in LDS (the usual case)
+typedef const uint32_t* TablePtrG;               // tables too large for LDS: read from global memory (L1 / L2)
 
 // ---- a lane's input: its string, the byte window, what it knows about runs and periodic regions ----------------------------------
 // (device_common.h's Input, without per-lane pointers: what is the same for every lane of the wave stays in scalar registers)
@@ -319,7 +320,7 @@ struct Aut {
     uint32_t cmap, vinfo, vc, vb, ee;      // word offsets into the table block
     uint32_t nc, vbits, start;
 };
-WALK_DEV void aut_load(Aut& a, TablePtr T, uint32_t at) {
+template <class TP> WALK_DEV void aut_load(Aut& a, TP T, uint32_t at) {
     a.cmap = at + T[at + 5]; a.vinfo = at + T[at + 6]; a.vc = at + T[at + 7]; a.vb = at + T[at + 8]; a.ee = at + T[at + 9];
     a.nc = T[at + 2]; a.vbits = T[at + 1]; a.start = T[at + 4];
 }
@@ -580,8 +581,8 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
     }
 }
 
-template <int K>
-WALK_DEV void ee_decode(TablePtr T, uint32_t at, bool p, uint32_t& e0, uint32_t& actions, uint32_t& cm, uint32_t& com, uint32_t& rdm) {
+template <int K, class TP>
+WALK_DEV void ee_decode(TP T, uint32_t at, bool p, uint32_t& e0, uint32_t& actions, uint32_t& cm, uint32_t& com, uint32_t& rdm) {
     e0 = p ? T[at] : 0u;
     const uint32_t e1 = p ? T[at + 1] : 0u;
     if (Lay<K>::EEW == 2) {
@@ -610,8 +611,8 @@ WALK_DEV void frame_state(const Ent<U, K>& E, U pos, uint32_t cm, uint32_t com, 
 #ifndef WALK_STEP_ATTR
 #define WALK_STEP_ATTR WALK_DEV
 #endif
-template <class U, int K, bool REV>
-WALK_STEP_ATTR void walk_step(const Store& st, TablePtr T, const Aut& au, WIn& in, uint32_t cur, uint32_t n_cur, uint32_t& n_next,
+template <class U, int K, bool REV, class TP>
+WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uint32_t cur, uint32_t n_cur, uint32_t& n_next,
                         const U i, const U len, const uint32_t ch, const bool final_pass, const bool active, const bool dual_lane,
                         bool& accept, bool& fits, tb_t& TB) {
     StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
@@ -650,7 +651,7 @@ WALK_STEP_ATTR void walk_step(const Store& st, TablePtr T, const Aut& au, WIn& i
                 const bool p = here && j < bcnt;
                 if (p) WALK_EV(1);
                 uint32_t e0, actions, cm, com, rdm;
-                ee_decode<K>(T, au.ee + (bbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
+                ee_decode<K, TP>(T, au.ee + (bbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
                 const uint32_t tvid = e0 >> 9, tfn = (e0 >> 5) & 15u, cell = (e0 >> 1) & 15u;
                 Ent<U, K> s = E;                                     // (most edges start from the entry's own cells)
                 if (__any(p && (cm | rdm) != 0u)) frame_state<U, K>(E, pos, cm, com, rdm, s);
@@ -685,7 +686,7 @@ WALK_STEP_ATTR void walk_step(const Store& st, TablePtr T, const Aut& au, WIn& i
                 const bool p = wait && j < ccnt;
                 if (p) WALK_EV(6);
                 uint32_t e0, actions, cm, com, rdm;
-                ee_decode<K>(T, au.ee + (cbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
+                ee_decode<K, TP>(T, au.ee + (cbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
                 Ent<U, K> t;
                 frame_state<U, K>(E, pos, cm, com, 0u, t);
                 insert<U, K>(cx, p, e0 >> 9, au.vbits, mkp(pos, (e0 >> 5) & 15u), TIE_WAIT + node, t);
@@ -832,8 +833,8 @@ WALK_DEV unsigned long long wv_clock() { return __builtin_readcyclecounter(); }
 #endif
 
 // Feeder::take(want, sid): hands the next string index to every lane that wants one; returns false when the batch is exhausted
-template <int K, bool REV, class Feeder>
-WALK_DEV void walk_wave(const Batch& b, TablePtr T, const Store& st, WALK_LDS uint64_t* rt_cache, Feeder& feed, WaveStats* stats) {
+template <int K, bool REV, class Feeder, class TP>
+WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t* rt_cache, Feeder& feed, WaveStats* stats) {
     WIn in;
     in.bytes = b.bytes; in.total16 = (b.offsets[b.n] + 15u) & ~(uint64_t)15; in.regions = b.regions; in.rtc = rt_cache;
     w_reset(in, 0, 0, 0);
@@ -935,12 +936,12 @@ WALK_DEV void walk_wave(const Batch& b, TablePtr T, const Store& st, WALK_LDS ui
             in.dual_p = p2 ? pp : 0u;
             (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the region
             (void)eq(di, dlen, TB);
-            walk_step<Dual, K, REV>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB);
+            walk_step<Dual, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB);
             in.dual_p = 0u;
             WALK_LAP(t_dual);
         } else {
             bool f2 = true;
-            walk_step<uint32_t, K, REV>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB);
+            walk_step<uint32_t, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB);
             WALK_LAP(t_plain);
         }
         cur ^= 1u;

@@ -23,9 +23,9 @@ static int env_int(const char* name, int dflt) {
     return e && *e ? atoi(e) : dflt;
 }
 
-bool walk_selected() {
+int walk_mode() {
     const char* e = getenv("MFA_WALK");
-    return e && e[0] == 't';                                  // "table"; anything else: the generated kernels
+    return !e ? 0 : e[0] == 't' ? 1 : e[0] == 'j' ? 2 : 0;     // "table" / "jit"; anything else: automatic
 }
 
 static size_t wave_words(uint32_t K, uint32_t C) {
@@ -50,6 +50,9 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     a.counter = d_counter;
     a.table_words = p.table_words;
     a.shared_words = (p.table_words + 63u) & ~63u;
+    // tables beyond a third of the LDS (or forced: development) stay in global memory
+    L.tables_global = a.shared_words > 160u * 1024u / 4u / 3u || getenv("MFA_WALK_TABLES_GLOBAL") != nullptr;
+    if (L.tables_global) a.shared_words = 0;
     a.n_seg = n_seg;
     for (uint32_t k = 0; k <= n_seg; k++) a.seg_first[k] = seg_first[k];
     for (uint32_t k = 0; k < n_seg; k++) a.seg_table[k] = seg_table[k];
@@ -244,7 +247,7 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
     int rc = mixed_device(mx, device, &d);
     if (rc != MFA_OK) return rc;
     hipStream_t cs = (hipStream_t)stream;
-    const bool table = walk_selected() && mx->table_ok;
+    const bool table = walk_mode() != 2 && mx->table_ok;      // the table engine unless the generated kernels are asked for
     // groups: ranges of strings, cut at fractions of the batch (a segment may straddle a cut).  Decreasing sizes: the walk of the
     // last group is what the call ends with.
     std::vector<uint64_t> cut{0};

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MFA_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "csrc", "libmfa_hip.so")      # (the override: development builds)
 
 OK = 0
-KERNEL_NONE, KERNEL_GENERIC, KERNEL_SPECIALISED, KERNEL_TABLE, KERNEL_WALK = 0, 1, 2, 3, 4
+KERNEL_NONE, KERNEL_WALK, KERNEL_SPECIALISED, KERNEL_TABLE = 0, 1, 2, 3
 ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_TOO_LONG, ERR_JIT = -1, -2, -3, -4, -5, -6, -7, -8
 
 EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_image_specialize", "mfa_match_batch",

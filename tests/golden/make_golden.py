@@ -36,7 +36,22 @@ EXAMPLES = {
     8: ("(({a*}:1|b)(&1|b))*", ["a", "b", "a"], "c", "bb"),
     9: ("(({aa*b}:1(&1)*)|b(b|a*)*)*", ["bbaaa"], "c", ""),
     10: ("({a*}:1b|b&1)*c&1", ["aababba"], "cab", ""),
+    # test/example_11..17: regexp.txt line 1, pump.txt (no README row, no timing files)
+    11: ("({a*}:1b&1b)*", ["aa", "b", "aa"], "bbc", ""),
+    12: ("(({a*}:1b&1b)*)*", ["aa", "b", "aa"], "bbc", ""),
+    13: ("ba{aa*}:1a&1*", ["a", "a", "a"], "b", "ba"),
+    14: ("{(a*|b*)}:1b(&1|b)*", ["b", "b", "b", "b", "b"], "bc", ""),
+    15: ("{a*}:1c{a*}:2c(&1|&2)*", ["aa"], "b", "aacaac"),
+    16: ("({a*}:1&1|(a*|b)a)*", ["baaaa"], "b", ""),
+    17: ("(&1{a*}:1|(a*|b)a)*", ["baaaa"], "b", ""),
 }
+
+# regexes whose side-effect files (the *.dot files compile() leaves in the working directory, regex.cpp:287,294,311,331; the
+# rewrite trace `-log` writes to log.txt, bnf.cpp:10,894-897) are kept byte for byte: (name, regex, mode)
+SIDE = [("ex1_plain", EXAMPLES[1][0], "plain"), ("ex3_reverse", EXAMPLES[3][0], "reverse"), ("ex5_bnf", EXAMPLES[5][0], "bnf"),
+        ("ex6_reverse", EXAMPLES[6][0], "reverse"), ("ex10_plain", EXAMPLES[10][0], "plain"), ("nfa_abb_plain", "(a|b)*abb", "plain"),
+        ("ex14_reverse", EXAMPLES[14][0], "reverse")]
+LOGGED = ["{a*}:1c{&1}:2c(&1|&2)*", "{{a*}:1(&1)*}:2b&2a*", "({a*}:1b|&1)*", "(({a*}:1|b)(&1|b))*", "({a*}:1b|b&1)*c&1"]
 
 # extra memory regexes (test/bnf_examples.txt column 1, test_inputs.txt) -- plain mode only
 EXTRA_MFA = {
@@ -133,9 +148,11 @@ def run(args, stdin_text=None, cwd=None):
 
 
 def main():
+    import sys
+    new_only = "--new-only" in sys.argv      # keep the answers that exist (they are the reference's: regenerating them changes nothing)
     if not os.path.exists(HARNESS):
         raise SystemExit("build oracle/_ref/ref_harness first (make -C oracle ref)")
-    for d in ("images", "strings", "results", "front"):
+    for d in ("images", "strings", "results", "front", "side"):
         os.makedirs(os.path.join(HERE, d), exist_ok=True)
     sets = string_sets()
     for name, strs in sets.items():
@@ -153,7 +170,14 @@ def main():
             automata.append({"name": "nfa_%s_%s" % (key, mode), "regex": regex, "mode": mode,
                              "sets": ["abc7", "rnd", "odd"]})
     with tempfile.TemporaryDirectory() as tmp:       # compile() drops *.dot files into cwd
+        old = {}
+        if new_only and os.path.exists(os.path.join(HERE, "manifest.json")):
+            with open(os.path.join(HERE, "manifest.json")) as f:
+                old = {a["name"]: a for a in json.load(f)["automata"]}
         for a in automata:
+            if a["name"] in old and all(os.path.exists(os.path.join(HERE, "results", "%s.%s.bits" % (a["name"], s))) for s in a["sets"]):
+                a["header"] = old[a["name"]]["header"]
+                continue
             dump = run(["dump", a["mode"], a["regex"]], cwd=tmp)
             a["header"] = run(["header", a["mode"], a["regex"]], cwd=tmp)
             with open(os.path.join(HERE, "images", a["name"] + ".dump"), "w") as f:
@@ -166,6 +190,20 @@ def main():
                 with open(os.path.join(HERE, "results", "%s.%s.bits" % (a["name"], s)), "w") as f:
                     f.write(bits + "\n")
             print(a["name"], "ok", flush=True)
+        # side-effect files of compile(), and the -log trace
+        for name, regex, mode in SIDE:
+            with tempfile.TemporaryDirectory() as side:
+                run(["dump", mode, regex], cwd=side)
+                for fn in sorted(os.listdir(side)):
+                    with open(os.path.join(side, fn), "rb") as f, open(os.path.join(HERE, "side", "%s.%s" % (name, fn)), "wb") as g:
+                        g.write(f.read())
+        for k, regex in enumerate(LOGGED):
+            with tempfile.TemporaryDirectory() as side:
+                run(["frontlog", regex], cwd=side)
+                with open(os.path.join(side, "log.txt"), "rb") as f, open(os.path.join(HERE, "side", "log%d.txt" % k), "wb") as g:
+                    g.write(f.read())
+        with open(os.path.join(HERE, "side", "logged.txt"), "w") as f:
+            f.write("".join(r + "\n" for r in LOGGED))
         # front-end KATs: the REPL body on every regex we use (BNF / Reverse strings)
         lines = []
         seen = set()

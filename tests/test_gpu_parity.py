@@ -26,17 +26,20 @@ def gpu_match(img, strings):
     return res.cpu().numpy()
 
 
-@pytest.mark.parametrize("jit", ["specialised", "generic"])
+def use_engine(monkeypatch, engine):
+    """MFA_WALK: "table" = the table-driven walk kernel (walk.hip), "specialised" = the kernel generated for the automaton"""
+    monkeypatch.setenv("MFA_WALK", "table" if engine == "table" else "jit")
+
+
+@pytest.mark.parametrize("jit", ["specialised", "table"])
 @pytest.mark.parametrize("auto", MANIFEST["automata"], ids=lambda a: a["name"])
 def test_golden(auto, jit, monkeypatch):
-    """Both MFA kernels: the automaton-specific one (where the automaton is small enough) and the
-    table-driven one (MFA_JIT=0)."""
+    """Both MFA kernels: the table-driven walk (every automaton) and the automaton-specific one, against the reference's answers."""
     blob = image.blob_from_dump(oracle_lib.load_dump(auto["name"]))
     is_mfa = image.blob_info(blob)["kind"] == image.KIND_MFA
-    if jit == "generic":
-        if not is_mfa:
-            pytest.skip("memory-less automata have one kernel")
-        monkeypatch.setenv("MFA_JIT", "0")
+    if jit == "table" and not is_mfa:
+        pytest.skip("memory-less automata have one kernel")
+    use_engine(monkeypatch, jit)
     img = capi.Image(blob)
     for sset in auto["sets"]:
         strings = oracle_lib.load_set(sset)
@@ -48,8 +51,8 @@ def test_golden(auto, jit, monkeypatch):
     kern = img.info()["last_kernel"]
     if not is_mfa:
         assert kern == capi.KERNEL_TABLE
-    elif jit == "generic":
-        assert kern == capi.KERNEL_GENERIC
+    elif jit == "table":
+        assert kern == capi.KERNEL_WALK
     else:
         assert kern == capi.KERNEL_SPECIALISED          # every fixture automaton has a specialised kernel
     img.close()
@@ -340,7 +343,7 @@ def _front_end_blob(regex, tmp_path, flag="-mfa"):
 @pytest.mark.parametrize("seed", range(3))
 def test_random_regexes_on_gpu(seed, tmp_path, monkeypatch):
     """Automata nobody has seen before: random regexes of the README grammar through the host front-end, matched by
-    the table-driven kernel (all of them) and by a freshly generated specialised kernel (the first one per seed),
+    the table-driven walk (all of them) and by a freshly generated specialised kernel (the first one per seed),
     against the CPU restatement."""
     import random
     from test_frontend_fuzz import rand_regex
@@ -360,8 +363,8 @@ def test_random_regexes_on_gpu(seed, tmp_path, monkeypatch):
         strings += [(("".join(rng.choice("ab") for _ in range(rng.randint(1, 3)))) * rng.randint(1, 400) + rng.choice(["", "a", "c"])).encode()
                     for _k in range(60)]
         want = oracle_lib.OracleImage(blob).match(strings)
-        for mode in (["generic", "specialised"] if done == 0 else ["generic"]):
-            monkeypatch.setenv("MFA_JIT", "0" if mode == "generic" else "1")
+        for mode in (["table", "specialised"] if done == 0 else ["table"]):
+            use_engine(monkeypatch, mode)
             try:
                 img = capi.Image(blob)
             except capi.MfaError as e:
@@ -386,6 +389,7 @@ def test_acceleration_changes_nothing_on_the_bench_corpus(ex, monkeypatch):
     ws = (np.arange(n) % 2) == 0
     d_bytes, d_off = corpus.device_batch(ex, sizes, ws, torch.device("cuda", 0))
     blob = image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex))
+    monkeypatch.setenv("MFA_WALK", "jit")
     img = capi.Image(blob)
     monkeypatch.setenv("MFA_ACCEL", "1")
     fast = img.match_tensors(d_bytes, d_off).clone()
@@ -394,11 +398,17 @@ def test_acceleration_changes_nothing_on_the_bench_corpus(ex, monkeypatch):
     slow = img.match_tensors(d_bytes, d_off).clone()
     torch.cuda.synchronize()
     assert torch.equal(fast, slow)
-    monkeypatch.setenv("MFA_JIT", "0")
-    m = 600
-    generic = capi.Image(blob).match_tensors(d_bytes, d_off[:m + 1].clone())
+    # the other engine, accelerated and executing every step (a prefix of the batch)
+    monkeypatch.setenv("MFA_ACCEL", "1")
+    monkeypatch.setenv("MFA_WALK", "table")
+    other = capi.Image(blob).match_tensors(d_bytes, d_off).clone()
     torch.cuda.synchronize()
-    assert torch.equal(generic, fast[:m])
+    assert torch.equal(other, fast)
+    monkeypatch.setenv("MFA_ACCEL", "0")
+    m = 600
+    plain = capi.Image(blob).match_tensors(d_bytes, d_off[:m + 1].clone())
+    torch.cuda.synchronize()
+    assert torch.equal(plain, fast[:m])
     # and the short ones among them against the CPU restatement
     short = [k for k in range(n) if sizes[k] <= 3000][:40]
     strings = corpus.host_strings(ex, sizes[short], ws[short])
@@ -424,8 +434,8 @@ def test_more_than_four_cells(regex, tmp_path, monkeypatch):
     strings += [b"abcaabbccabc" + b"cbccbbaacba"[::-1], b"abc" + b"a" * 40 + b"b" * 30 + b"c" * 20 + b"ab" + b"c" * 25 + b"c" * 25 + b"ba" + b"c" * 20 + b"b" * 30 + b"a" * 40 + b"cba",
                 b"abc" + b"ab" + b"ba" + b"cba", b"abcaabbccabcccbaccbbaacba"]
     want = oracle_lib.OracleImage(blob).match(strings)
-    for mode in ("generic", "specialised"):
-        monkeypatch.setenv("MFA_JIT", "0" if mode == "generic" else "1")
+    for mode in ("table", "specialised"):
+        use_engine(monkeypatch, mode)
         got = gpu_match(capi.Image(blob), strings)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, "%s: %d mismatches, first %r want %d" % (mode, bad.size, strings[bad[0]], want[bad[0]])
@@ -433,8 +443,7 @@ def test_more_than_four_cells(regex, tmp_path, monkeypatch):
 
 
 # nondeterministic automata with seven cells: several ways to the same node and position with different cell contents, and reads
-# of cells that were never set (mfa.cpp:148-160 recurses once per such cell: the table-driven kernel's tie-break key has one
-# 5-bit digit per level and does not fit 32 bits from six cells on)
+# of cells that were never set (mfa.cpp:148-160 recurses once per such cell)
 MANY_CELLS_TIES = ["({a}:1|b)({a}:2|b)({a}:3|b)({a}:4|b)({a}:5|b)({a}:6|b)({a}:7|b)(&1|&2)(&3|&4)(&5|&6)&7",
                    "{a*}:1{a*}:2{a*}:3{a*}:4{a*}:5{a*}:6{a*}:7b&7&6&5&4&3&2&1"]
 
@@ -455,8 +464,8 @@ def test_many_cells_tie_breaks(regex, tmp_path, monkeypatch):
             n = rng.randint(0, 9)
             strings.append(("a" * n + "b" + "a" * (n if rng.random() < 0.7 else rng.randint(0, 9))).encode())
     want = oracle_lib.OracleImage(blob).match(strings)
-    for mode in ("generic", "specialised"):
-        monkeypatch.setenv("MFA_JIT", "0" if mode == "generic" else "1")
+    for mode in ("table", "specialised"):
+        use_engine(monkeypatch, mode)
         got = gpu_match(capi.Image(blob), strings)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, "%s: %d mismatches, first %r want %d" % (mode, bad.size, strings[bad[0]], want[bad[0]])
@@ -498,3 +507,105 @@ def test_full_length_reversed_strings(ex):
     want = oracle_lib.OracleImage(blob).match(strings)
     got = gpu_match(capi.Image(blob), strings)
     assert list(got) == list(want)
+
+
+# ---- the table-driven walk: what only it can do ------------------------------------------------------------------------------------
+def test_mixed_batch_in_one_call(monkeypatch):
+    """mfa_match_mixed: ONE batch, ten segments, ten automata (the 10-example attack corpus at a small size), against the oracle
+    and against matching every segment by itself; both engines behind the call."""
+    import torch
+    from mfa_amd import corpus
+    layout = [2, 5, 3, 8, 9, 10, 6, 4, 1, 7]
+    n_per = 3000
+    dev = torch.device("cuda", 0)
+    parts_b, parts_o, seg, pos_b, blobs, samples = [], [], [0], 0, [], []
+    for ex in layout:
+        sizes = corpus.pump_sizes(n_per, 0x5EED0004 + ex, 64, 20000)
+        ws = (np.arange(n_per) % 2) == 0
+        b, o = corpus.device_batch(ex, sizes, ws, dev)
+        nb = int(o[-1].item())
+        parts_b.append(b[:nb]); parts_o.append(o[:-1] + pos_b); pos_b += nb; seg.append(seg[-1] + n_per)
+        blobs.append(image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex)))
+        short = [k for k in range(n_per) if sizes[k] <= 2000][:60]
+        samples.append((short, corpus.host_strings(ex, sizes[short], ws[short])))
+    bytes_all = torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=dev)])
+    off_all = torch.cat(parts_o + [torch.tensor([pos_b], dtype=torch.int64, device=dev)])
+    results = {}
+    for engine in ("table", "specialised"):
+        use_engine(monkeypatch, engine)
+        images = [capi.Image(b) for b in blobs]
+        mx = capi.Mixed(images)
+        for cuts in ("0.3,0.6,0.8,0.9", "0.17,0.55", ""):          # cuts inside segments, and one group
+            monkeypatch.setenv("MFA_MIXED_CUTS", cuts)
+            res = mx.match_tensors(bytes_all, off_all, seg).clone()
+            torch.cuda.synchronize()
+            results[(engine, cuts)] = res
+        for k in range(len(layout)):                                # segment by segment through the single-automaton entry point
+            alone = images[k].match_tensors(bytes_all, off_all[seg[k]:seg[k + 1] + 1])
+            torch.cuda.synchronize()
+            assert torch.equal(alone, results[(engine, "")][seg[k]:seg[k + 1]]), (engine, layout[k])
+        mx.close()
+    first = next(iter(results.values()))
+    for key, r in results.items():
+        assert torch.equal(r, first), key
+    for k, (short, strings) in enumerate(samples):
+        want = oracle_lib.OracleImage(blobs[k]).match(strings)
+        got = first[seg[k]:seg[k + 1]][short].cpu().numpy()
+        assert np.array_equal(got, want), layout[k]
+
+
+def test_more_than_128_nodes(tmp_path, monkeypatch):
+    """beyond the generated kernels' 128 nodes: a memory automaton with several hundred nodes (a long literal chain around a
+    back-reference) walked by the table-driven kernel, against the CPU restatement"""
+    import random
+    rng = random.Random(128)
+    chain = "".join(rng.choice("ab") for _ in range(300))
+    regex = "{a*}:1" + chain + "&1" + "(a|b)*"
+    blob = _front_end_blob(regex, tmp_path)
+    assert image.blob_info(blob)["n_nodes"] > 128
+    strings = []
+    for n in (0, 1, 5, 70, 400):
+        strings += [("a" * n + chain + "a" * n).encode(), ("a" * n + chain + "a" * n + "abba").encode(), ("a" * n + chain + "a" * (n + 1) + "b").encode(),
+                    ("a" * n + chain[:-1] + "a" * n).encode()]
+    want = oracle_lib.OracleImage(blob).match(strings)
+    img = capi.Image(blob)
+    got = gpu_match(img, strings)
+    assert img.info()["last_kernel"] == capi.KERNEL_WALK
+    assert list(got) == list(want) and 0 < want.sum() < len(strings)
+
+
+def _images_of(name_filter):
+    return [a["name"] for a in MANIFEST["automata"] if name_filter(a["name"])]
+
+
+@pytest.mark.parametrize("name", _images_of(lambda n: n.startswith("ex") and n.split("_")[1] in ("plain", "bnf", "reverse")))
+def test_long_strings_every_image(name, monkeypatch):
+    """Every image of the ten examples (plain, -bnf, -reverse) on at least 100 strings of 32-64 KiB: pumped with and without the
+    suffix, with one to three damaged bytes at random offsets, and cut-and-spliced halves -- where cell reads jump the farthest
+    (mfa.cpp:177-191).  Against the CPU restatement, on both engines."""
+    from mfa_amd import corpus
+    ex = int("".join(c for c in name.split("_")[0] if c.isdigit()))
+    regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+    rng = np.random.default_rng(1000 + ex)
+    strings = []
+    for k in range(26):
+        n = int(rng.integers(32768, 65536))
+        base = prefix + corpus.pumped_string(n, pump)
+        for ws in (False, True):
+            s = (base + (suffix if ws else "")).encode()
+            strings.append(s)
+            d = bytearray(s)
+            for _ in range(int(rng.integers(1, 4))):
+                d[int(rng.integers(0, len(d)))] = int(rng.choice(list(b"abc")))
+            strings.append(bytes(d))
+        h = len(base) // 2
+        cut = int(rng.integers(1, h))
+        strings.append((base[:h] + base[cut:]).encode())
+    assert len(strings) >= 100 and min(len(s) for s in strings) >= 32768
+    blob = image.blob_from_dump(oracle_lib.load_dump(name))
+    want = oracle_lib.OracleImage(blob).match(strings)
+    for engine in ("table", "specialised"):
+        use_engine(monkeypatch, engine)
+        got = gpu_match(capi.Image(blob), strings)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "%s %s: %d mismatches, first at string %d (len %d) want %d" % (name, engine, bad.size, bad[0], len(strings[bad[0]]), want[bad[0]])

@@ -263,3 +263,36 @@ def test_bench_line_smoke():
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and r["peak"] == 8000.0 and r["region_scan_kernel"]["launches_per_step"] >= 1
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["parity"] is True and c["cores"] >= 1
+    # parity at scale: a seeded 1 % of every example's strings, no length cap, against the CPU restatement
+    ps = d["parity_sample"]
+    assert ps["strings"] >= 10 * 30 and ps["mismatches"] == 0 and ps["max_len"] > 20000
+    assert c["parity_restatement"]["strings"] == ps["strings"]
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_rehearsal(scaling):
+    """The N > 1 path of bench.py in every GPU test run: two ranks on this one GPU over gloo (MFA_BENCH_REHEARSE=1; real runs
+    use one GPU per rank and RCCL).  Both ranks must show up in the line, every rank's bitmap must reach rank 0 (bench.py itself
+    checks rank 0's segment of the gathered vector against its local results), and under strong scaling the two ranks' strings
+    and bytes must add up to the job's ONE batch."""
+    import json
+    import subprocess
+    import sys
+    root = oracle_lib.ROOT
+    env = dict(os.environ)
+    env["MFA_BENCH_REHEARSE"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--strings-per-example", "3000", "--steps", "2", "--warmup", "1",
+                        "--no-secondary", "--no-cpu-baseline", "--scaling", scaling], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["scaling"] == scaling
+    assert len(d["bytes_by_rank"]) == 2 and min(d["bytes_by_rank"]) > 0 and len(d["strings_by_rank"]) == 2
+    if scaling == "strong":
+        assert sum(d["strings_by_rank"]) == 10 * 3000
+        lo, hi = sorted(d["bytes_by_rank"])
+        assert hi - lo <= 70000                                   # the cut is balanced by bytes (to within one string)
+    else:
+        assert d["strings_by_rank"] == [30000, 30000]
+
