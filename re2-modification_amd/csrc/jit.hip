@@ -72,7 +72,11 @@ bool jit_enabled(const HostImage& img) {
     const char* e = getenv("MFA_JIT");
     if (e && e[0] == '0') return false;
     // up to 272 slot registers in VGPRs, beyond that slot sets in LDS; the generated code keeps node sets in 128-bit masks
-    return img.h.kind == MFA_KIND_MFA && img.h.n_nodes <= 128u && jit_lanes(img) != 0;
+    // ... and unrolls every edge, through every chain of absent-cell edges: beyond a few hundred edges, or 1.5 MB of generated
+    // source, the compiler takes longer than any batch (ex. 15 -reverse: 939 edges; ex. 15 -bnf: 69 edges, 4 MB of source)
+    if (!(img.h.kind == MFA_KIND_MFA && img.h.n_nodes <= 128u && img.h.n_edges <= 400u && jit_lanes(img) != 0)) return false;
+    if (img.jit_source_ok < 0) img.jit_source_ok = jit_generate_source(img).size() <= 1536u * 1024u ? 1 : 0;
+    return img.jit_source_ok == 1;
 }
 
 bool jit_cached(const HostImage& img) {

@@ -30,6 +30,7 @@ struct HostImage {
     uint8_t               byte_class[256] = {0};
     std::vector<uint16_t> dfa_trans;   // [dfa_states][n_classes]
     std::vector<uint8_t>  dfa_accept;  // [dfa_states]: finish is in the set after the final pass
+    mutable int           jit_source_ok = -1;      // MFA kind: the generated kernel's source is of a size a compiler finishes (jit.hip; -1 = not looked at)
 };
 
 int parse_blob(const void* blob, size_t n_bytes, HostImage& out);   // MFA_OK / MFA_ERR_*

@@ -54,7 +54,8 @@ def test_golden(auto, jit, monkeypatch):
     elif jit == "table":
         assert kern == capi.KERNEL_WALK
     else:
-        assert kern == capi.KERNEL_SPECIALISED          # every fixture automaton has a specialised kernel
+        # every fixture automaton has a specialised kernel, except those the generator refuses (hundreds of edges to unroll)
+        assert kern == (capi.KERNEL_SPECIALISED if img.specialize() else capi.KERNEL_WALK)
     img.close()
 
 
