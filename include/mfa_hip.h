@@ -85,7 +85,8 @@ int  mfa_image_prepare(mfa_image_t* img, int device);
  * as a code object next to the library (or in $MFA_JIT_CACHE).  This call does that now; it is host-only
  * work and needs no GPU, so caches can be built ahead of time.  A match call uses the specialised kernel
  * when its code object is in the cache and never waits for a compiler (MFA_WALK=table / MFA_WALK=jit force
- * one kernel or the other; MFA_JIT=0 disables specialised kernels).  MFA_ERR_UNSUPPORTED: the automaton
+ * one kernel or the other; MFA_JIT=0 disables specialised kernels; MFA_ACCEL=0 or MFA_REGIONS=0: no region pass,
+ * every step is executed -- A/B runs).  MFA_ERR_UNSUPPORTED: the automaton
  * is too large for a specialised kernel; MFA_ERR_JIT: the compiler failed. */
 int  mfa_image_specialize(mfa_image_t* img);
 

@@ -143,10 +143,10 @@ static Compiled compile_mode(const std::string& mode, std::string regex) {
     std::streambuf* old = std::cout.rdbuf(sink.rdbuf());
     g_in_ref = true;
     Regexp* re = Regexp::parse_regexp(regex);
-    if (mode == "plain" || mode == "bnf" || mode == "reverse") {
+    if (mode == "plain" || mode == "bnf" || mode == "reverse" || mode == "ssnf" || mode == "all") {
         bool is_mfa = false;
-        bool rev = (mode == "reverse"), bnf = (mode != "plain");
-        Automata* a = re->compile(is_mfa, rev, bnf, false);
+        bool rev = (mode == "reverse" || mode == "all"), bnf = (mode == "bnf" || mode == "reverse" || mode == "all");
+        Automata* a = re->compile(is_mfa, rev, bnf, mode == "ssnf" || mode == "all");
         if (is_mfa) c.mfa = static_cast<MFA*>(a); else c.nfa = a;
     } else if (mode == "thompson") {
         c.nfa = re->to_binary_tree()->toThomson();

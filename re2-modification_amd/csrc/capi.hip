@@ -178,7 +178,7 @@ int mfa_image_specialize(mfa_image_t* img) {
 }
 
 static bool regions_enabled() {
-    const char* e = getenv("MFA_REGIONS");                      // MFA_REGIONS=0: no region pass, the walk measures regions itself (A/B runs)
+    const char* e = getenv("MFA_REGIONS");                      // MFA_REGIONS=0: no region pass and no table: every step is executed (A/B runs)
     const char* a = getenv("MFA_ACCEL");
     return !(e && e[0] == '0') && !(a && a[0] == '0');
 }
@@ -213,6 +213,12 @@ static int match_impl(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* 
     LaunchCtx* cx = nullptr;
     rc = ctx_acquire(*ds, stream, &cx);
     if (rc != MFA_OK) return rc;
+    // whatever happens below, the context's `done` event is recorded behind what was enqueued: a launch on another stream must not
+    // be handed this context (its counter, scratch area and table) while a kernel of this call may still be using it
+    struct DoneGuard {
+        LaunchCtx* cx; void* stream;
+        ~DoneGuard() { (void)hipEventRecord((hipEvent_t)cx->ev_done, (hipStream_t)stream); }
+    } done_guard{cx, stream};
     if (table_walk) {
         img->last_kernel = MFA_KERNEL_WALK;
         if (own_regions && regions_enabled()) {
@@ -249,7 +255,6 @@ static int match_impl(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* 
         img->last_kernel = MFA_KERNEL_TABLE;
         rc = launch_dfa_walk(img->host, *ds, *cx, d_bytes, d_offsets, n, d_results, stream);
     }
-    HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_done, (hipStream_t)stream));
     return rc;
 }
 

@@ -91,8 +91,15 @@ std::string jit_compile(const HostImage& img, std::string* err) {
     const std::string text = jit_generate_source(img);
     const std::string dir = cache_dir(), key = source_key(text);
     const std::string obj = dir + "/" + key + ".hsaco";
-    if (file_exists(obj)) return obj;
     mkdir(dir.c_str(), 0700);
+    {   // the cache holds code that is loaded onto the GPU: it must be a directory of ours that nobody else can write to
+        struct stat st;
+        if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 022) != 0) {
+            if (err) *err = "cache directory " + dir + " is not a directory owned by this user and closed to others";
+            return "";
+        }
+    }
+    if (file_exists(obj)) return obj;
     static std::atomic<unsigned> serial{0};
     char tmpl[64];
     snprintf(tmpl, sizeof tmpl, ".tmp%d_%u", (int)getpid(), serial.fetch_add(1));

@@ -111,8 +111,17 @@ __device__ __forceinline__ void emit(RegionState& st, uint32_t lane, int32_t x, 
 #pragma unroll
     for (int d = 1; d <= 4; d++)
         if (d < Q && Q % d == 0 && st.cand_x[d] <= x + 1 && st.cand_y[d] >= y - 1) return;
-    if (lane == st.ncand) { st.cq = Q; st.cx = x; st.cy = y; }
-    st.ncand++;
+    if (st.ncand < 64u) {
+        if (lane == st.ncand) { st.cq = Q; st.cx = x; st.cy = y; }
+        st.ncand++;
+        return;
+    }
+    // More candidates than lanes (text made of hundreds of medium runs): the new one takes the place of the shortest if it is longer,
+    // so that a long periodic stretch BEHIND such text is still in the table (the walk jumps over what the table holds and executes
+    // everything else step by step).  The table then carries the overflow flag (ncand stays at 64).
+    uint32_t key = ((uint32_t)(st.cy - st.cx) << 6) | lane;                // length in blocks (< 2^20) | lane
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(key, o); key = t < key ? t : key; }
+    if ((uint32_t)(y - x) > (key >> 6) && lane == (key & 63u)) { st.cq = Q; st.cx = x; st.cy = y; }
 }
 
 // book-keeping of one row for one period: dirty = ballot of dirty blocks, base = block number of lane 0
@@ -246,8 +255,11 @@ __device__ __forceinline__ uint2 row_tail(const Row& r) {
                       (uint32_t)__builtin_amdgcn_update_dpp((int)r.y[1], (int)r.x[1], 0x130, 0xf, 0xf, false));
 }
 // r was requested before the YOUNGER rows requested last: once at most their loads (two each) are outstanding, r has arrived
-template <int YOUNGER>
-__device__ __forceinline__ void row_wait_older(Row& r) { asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.x), "+v"(r.y) : "n"(2 * YOUNGER) : "memory"); }
+template <int YOUNGER, bool SAFE>
+__device__ __forceinline__ void row_wait_older(Row& r) {
+    if (SAFE) asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.x), "+v"(r.y) :: "memory");      // development: wait for everything (MFA_REGION_SAFE_WAITS=1)
+    else asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r.x), "+v"(r.y) : "n"(2 * YOUNGER) : "memory");
+}
 __device__ __forceinline__ void row_wait_all(Row& r) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(r.x), "+v"(r.y) :: "memory"); }
 
 // one row: x = this lane's block, y = the 8 bytes behind it
@@ -392,7 +404,7 @@ constexpr int kRegionDepth = 2;      // 3 and 4 are more robust alone at low occ
 // before the current string's candidates are resolved) was built and measured: 4.48 ms against 4.30 ms for this one on the
 // headline shard, and worse beside the walk kernels -- with eight waves per SIMD the dispatcher's own refill hides a wave's
 // start-up latencies as well as software pipelining does.
-template <int MODE, int DEPTH>
+template <int MODE, int DEPTH, bool SAFE>
 __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
                                                              uint64_t* __restrict__ table) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -410,9 +422,8 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
         Scan sc;
         scan_reset(sc);
         // DEPTH register sets in rotation, the loop unrolled by DEPTH (all indices are constants after unrolling): while a row is
-        // looked at, the DEPTH - 1 rows after it are in flight.  One exit, at the bottom.  More candidates than lanes to hold them
-        // (text made of hundreds of medium runs): the table would carry the overflow flag whatever comes, and the walk cannot skip
-        // much of such a string anyway -- the rest of it is not read.
+        // looked at, the DEPTH - 1 rows after it are in flight.  One exit, at the bottom.  (Every string is read to its end, also when it
+        // has more candidates than lanes to hold them: emit() then keeps the longest.)
         Row r[DEPTH];
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) { r[k].x = u32x4{0, 0, 0, 0}; r[k].y = u32x2{0, 0}; }
@@ -427,9 +438,9 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
             for (int k = 0; k < DEPTH; k++) {
                 if (go) {
                     row_request(sbase, g, row + k + DEPTH - 1, lane, r[(k + DEPTH - 1) % DEPTH]);
-                    row_wait_older<DEPTH - 1>(r[k]);
+                    row_wait_older<DEPTH - 1, SAFE>(r[k]);
                     scan_row(sc, lane, g, row + k, make_uint4(r[k].x[0], r[k].x[1], r[k].x[2], r[k].x[3]), row_tail(r[k]));
-                    go = sc.st.ncand < 64u && row + k + 1 < g.nrows;
+                    go = row + k + 1 < g.nrows;
                 }
             }
             more = go;
@@ -457,10 +468,15 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     const unsigned lds = el ? (unsigned)atoi(el) : 0u;
     const char* ed = getenv("MFA_REGION_DEPTH");                  // development: rows per wave in rotation (2, 3 or 4)
     const int depth = ed ? atoi(ed) : kRegionDepth;
-    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 3) hipLaunchKernelGGL((region_scan_kernel<0, 3>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    // development: MFA_REGION_SAFE_WAITS=1 waits for every outstanding load before a row is looked at, instead of counting on the
+    // order of the requests (tests/test_regions_gpu.py compares the tables of the two modes)
+    const char* es = getenv("MFA_REGION_SAFE_WAITS");
+    const bool safe = es && es[0] == '1';
+    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (safe) hipLaunchKernelGGL((region_scan_kernel<0, 2, true>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    else if (depth == 3) hipLaunchKernelGGL((region_scan_kernel<0, 3, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
     else return MFA_ERR_UNSUPPORTED;
     HIP_TRY(hipGetLastError());
     return MFA_OK;

@@ -289,6 +289,8 @@ public:
     list<string> doLAST();
     set<pair<string, string>> doFOLLOW();
     bool is_one_unambiguity();
+    BinaryTree* toSSNF();           // star normal form (bt/bt_ssnf.cpp:73-108)
+    BinaryTree* starBody();         // the same for a subtree that sits under an iteration (bt/bt_ssnf.cpp:18-71); nullptr: nothing left
 
     Automata* toThomson();
     Automata* toGlushkov();

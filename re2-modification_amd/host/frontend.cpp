@@ -309,14 +309,83 @@ Automata* Regexp::compile(bool& is_mfa, bool use_reverse, bool use_bnf, bool use
         cout << "1-\xd0\xbe\xd0\xb4\xd0\xbd\xd0\xbe\xd0\xb7\xd0\xbd\xd0\xb0\xd1\x87\xd0\xbd\xd0\xbe\xd1\x81\xd1\x82\xd1\x8c" << endl;
         return bt->toGlushkov();                                     // (toSSNF result discarded, regex.cpp:320-321)
     }
-    if (use_ssnf)
-        throw std::runtime_error("compile: -ssnf on a memory-less, not 1-unambiguous regex needs bt/bt_ssnf.cpp's "
-                                 "star normal form, which this build does not include yet");
-    Automata* rev = reverse()->to_binary_tree()->toGlushkov();
+    BinaryTree* rbt = reverse()->to_binary_tree();
+    if (use_ssnf) rbt = rbt->toSSNF();                              // the one place where the normal form is used (regex.cpp:326-328)
+    Automata* rev = rbt->toGlushkov();
     rev->is_reversed = true;
     rev->draw("reverse");
     if (rev->isDeterministic()) return rev;
     return bt->toThomson();
+}
+
+// =====================================================================================================
+// star normal form (reference bt/bt_ssnf.cpp): iterations of subtrees that produce the empty word are flattened,
+// e.g. (a*b*)* -> (a|b)*.  Only the reversed Glushkov automaton of a memory-less regex is built from it.
+// =====================================================================================================
+namespace {
+// a binary node one of whose children vanished is that child's sibling (both vanished: nothing)
+BinaryTree* without_empty_child(BinaryTree* t) {
+    if (!t->left) return t->right;
+    if (!t->right) return t->left;
+    return t;
+}
+BinaryTree* leaf_copy(const BinaryTree* t) {
+    BinaryTree* c = new BinaryTree(t->type);
+    c->rune = t->rune;
+    c->variable = t->variable;
+    return c;
+}
+}  // namespace
+
+BinaryTree* BinaryTree::toSSNF() {
+    switch (type) {
+        case literal: case reference: return leaf_copy(this);
+        case concatenationExpr: case alternationExpr: {
+            BinaryTree* t = new BinaryTree(type);
+            t->left = left->toSSNF();
+            t->right = right->toSSNF();
+            return without_empty_child(t);
+        }
+        case kleeneStar: case kleenePlus: {
+            BinaryTree* t = new BinaryTree(type);
+            t->child = child->starBody();
+            return t;
+        }
+        default: return this;                                       // epsilon, a named group: as they are
+    }
+}
+
+BinaryTree* BinaryTree::starBody() {
+    switch (type) {
+        case epsilon: return nullptr;
+        case literal: case reference: return leaf_copy(this);
+        case concatenationExpr: {
+            const bool le = left->epsilonProducing(), re = right->epsilonProducing();
+            BinaryTree* t = new BinaryTree(le && re ? alternationExpr : concatenationExpr);
+            if (!le && !re) { t->left = left; t->right = right; return t; }      // cannot be empty: the iteration around it stays as it is
+            if (le && re) {                                                       // both may be empty: under the star the order does not matter
+                t->left = left->starBody();
+                t->right = right->starBody();
+                return without_empty_child(t);
+            }
+            t->left = left->toSSNF();
+            t->right = right->toSSNF();
+            return t;
+        }
+        case alternationExpr: {
+            BinaryTree* t = new BinaryTree(alternationExpr);
+            t->left = left->toSSNF();
+            t->right = right->toSSNF();
+            return without_empty_child(t);
+        }
+        case kleeneStar: case kleenePlus: return child->starBody();              // an iteration under an iteration: its body
+        case backreferenceExpr: {
+            BinaryTree* t = new BinaryTree(backreferenceExpr);                    // (the reference does not carry the name over)
+            t->child = child->starBody();
+            return t;
+        }
+        default: return this;
+    }
 }
 
 // =====================================================================================================

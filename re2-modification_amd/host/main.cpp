@@ -59,7 +59,8 @@ int do_dump(int argc, char** argv) {
     else if (mode == "-mfa") { re->is_backref_correct(); mfa = re->to_binary_tree()->toMFA(); }
     else {
         bool is_mfa = false;
-        Automata* a = re->compile(is_mfa, mode == "-reverse", mode == "-bnf" || mode == "-reverse", false);
+        const bool all = mode == "-all";                   // -all = -bnf -reverse -ssnf (main.cpp:25-29)
+        Automata* a = re->compile(is_mfa, mode == "-reverse" || all, mode == "-bnf" || mode == "-reverse" || all, mode == "-ssnf" || all);
         if (is_mfa) mfa = static_cast<MFA*>(a); else nfa = a;
     }
     cout.rdbuf(old);

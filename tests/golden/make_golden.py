@@ -70,12 +70,16 @@ EXTRA_MFA = {
 }
 
 # memory-less regexes: (regex, [modes]); plain = what compile() picks (regex.cpp:315-342)
+# ssnf / all: compile() with the star normal form (bt/bt_ssnf.cpp; regex.cpp:325-334) / with -all = -bnf -reverse -ssnf (main.cpp:25-29)
 NFA = {
-    "abb": ("(a|b)*abb", ["plain", "thompson", "glushkov"]),
-    "third": ("(a|b)*a(a|b)(a|b)", ["plain", "thompson", "glushkov"]),
-    "dot": ("a.c*(b|.a)*", ["plain", "thompson", "glushkov"]),
-    "enum": ("[a-c]*abc", ["plain", "glushkov"]),
-    "alt3": ("(ab|b)(ab|ba)*c*", ["plain", "thompson", "glushkov"]),
+    "abb": ("(a|b)*abb", ["plain", "thompson", "glushkov", "ssnf", "all"]),
+    "third": ("(a|b)*a(a|b)(a|b)", ["plain", "thompson", "glushkov", "ssnf"]),
+    "dot": ("a.c*(b|.a)*", ["plain", "thompson", "glushkov", "ssnf"]),
+    "enum": ("[a-c]*abc", ["plain", "glushkov", "ssnf"]),
+    "alt3": ("(ab|b)(ab|ba)*c*", ["plain", "thompson", "glushkov", "ssnf"]),
+    "star1": ("(a*b*)*ab", ["plain", "ssnf"]),
+    "star2": ("((a*)*|b*)*a", ["plain", "ssnf"]),
+    "star4": ("((ab)*c*)*(a|b)", ["plain", "ssnf"]),
 }
 
 

@@ -13,7 +13,8 @@ DIPLOMA = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma
 with open(os.path.join(oracle_lib.GOLDEN, "manifest.json")) as f:
     MANIFEST = json.load(f)
 
-FLAG = {"plain": [], "thompson": ["-thompson"], "glushkov": ["-glushkov"], "mfa": ["-mfa"], "bnf": ["-bnf"], "reverse": ["-reverse"]}
+FLAG = {"plain": [], "thompson": ["-thompson"], "glushkov": ["-glushkov"], "mfa": ["-mfa"], "bnf": ["-bnf"], "reverse": ["-reverse"], "ssnf": ["-ssnf"],
+        "all": ["-all"]}
 SUPPORTED = [a for a in MANIFEST["automata"] if a["mode"] in FLAG]
 assert len(SUPPORTED) == len(MANIFEST["automata"])          # every fixture automaton: plain, -bnf and -reverse images included
 
@@ -74,19 +75,45 @@ def test_reverse_header_lines(tmp_path):
     assert "BNF" not in p.stdout and "1-" in p.stdout
 
 
-def test_rewrite_trace(tmp_path):
-    """`-log` leaves the rewrite trace in log.txt (bnf.cpp:10,894-897)"""
-    p = run(["x", "-log"], "{a*}:1c{&1}:2c(&1|&2)*\nexit\n", tmp_path)
+SIDE = os.path.join(oracle_lib.GOLDEN, "side")
+
+
+def logged_regexes():
+    with open(os.path.join(SIDE, "logged.txt")) as f:
+        return [l.rstrip("\n") for l in f if l.strip()]
+
+
+@pytest.mark.parametrize("k", range(len(logged_regexes())))
+def test_rewrite_trace(k, tmp_path):
+    """`-log` leaves the rewrite trace in log.txt (bnf.cpp:10,894-897): byte for byte what the reference writes"""
+    regex = logged_regexes()[k]
+    p = run(["x", "-log"], regex + "\nexit\n", tmp_path)
     assert p.returncode == 0 and p.stdout.startswith("BNF: ")
-    log = (tmp_path / "log.txt").read_text()
-    assert "distribute" in log or "open kleene" in log
+    with open(os.path.join(SIDE, "log%d.txt" % k), "rb") as f:
+        want = f.read()
+    assert (tmp_path / "log.txt").read_bytes() == want
 
 
-def test_dot_side_effect(tmp_path):
-    """compile() leaves mfa.dot behind like the reference (regex.cpp:311, mfa.cpp:28-61)."""
-    run(["-dump"], "({a*}:1&1)*\n", tmp_path)
-    dot = (tmp_path / "mfa.dot").read_text()
-    assert dot.startswith("digraph g {") and "0 -> 1 [label=\"a/o1/\"]" in dot and "0 -> 3 [label=\"ε/\"]" in dot
+def side_files():
+    """tests/golden/side/<automaton>.<file>: the files the reference's compile() leaves in its working directory"""
+    out = []
+    for fn in sorted(os.listdir(SIDE)):
+        if fn.endswith(".dot"):
+            name, rest = fn.split(".", 1)
+            out.append((name, rest))
+    return out
+
+
+@pytest.mark.parametrize("name,fn", side_files())
+def test_dot_side_effect(name, fn, tmp_path):
+    """compile() leaves mfa.dot / reverse_mfa.dot / reverse.dot behind like the reference (regex.cpp:287,294,311,331;
+    mfa.cpp:28-61, automata.cpp:34-66), byte for byte -- the MFA version's epsilon labels included."""
+    auto = next(a for a in MANIFEST["automata"] if a["name"] == name)
+    p = run(["-dump"] + FLAG[auto["mode"]], auto["regex"] + "\n", tmp_path)
+    assert p.returncode == 0, p.stderr
+    with open(os.path.join(SIDE, "%s.%s" % (name, fn)), "rb") as f:
+        want = f.read()
+    assert (tmp_path / fn).read_bytes() == want
 
 
 def test_example_runner_without_files(tmp_path):

@@ -70,8 +70,9 @@ def test_cli_match_contract(tmp_path):
     (main.cpp:42-44, matchers/match.cpp:21-31)."""
     import subprocess
     diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
-    flags = {"plain": [], "bnf": ["-bnf"], "reverse": ["-reverse"]}
-    for name in ("ex1_plain", "ex5_plain", "nfa_abb_plain", "nfa_third_plain", "ex3_reverse", "ex6_reverse", "ex2_bnf", "ex1_reverse"):
+    flags = {"plain": [], "bnf": ["-bnf"], "reverse": ["-reverse"], "ssnf": ["-ssnf"], "all": ["-all"]}
+    for name in ("ex1_plain", "ex5_plain", "nfa_abb_plain", "nfa_third_plain", "ex3_reverse", "ex6_reverse", "ex2_bnf", "ex1_reverse", "nfa_abb_all",
+                 "nfa_star1_ssnf", "ex14_reverse", "ex17_bnf"):
         auto = next(a for a in MANIFEST["automata"] if a["name"] == name)
         strings, want = [], []
         for sset in auto["sets"]:
@@ -111,7 +112,12 @@ def test_match_file_drivers(tmp_path):
     path.write_bytes(b"abb\naabb\nab\nbbbbabb\n")
     p = subprocess.run([diploma, "-match-file", "gt", str(path)], input=auto["regex"].encode() + b"\n", capture_output=True, cwd=tmp_path)
     assert p.returncode == 0, p.stderr
-    assert float(p.stdout.split()[0]) >= 0.0 and (tmp_path / "results.txt").exists()
+    assert float(p.stdout.split()[0]) >= 0.0
+    # results.txt: times only, `seconds,` like the reference's (match_mfa.cpp:40-41 writes one per string; a batch has one time), and
+    # the two drawings it leaves (match_mfa.cpp:18-19)
+    import re
+    assert re.fullmatch(r"([0-9.eE+-]+,)+", (tmp_path / "results.txt").read_text())
+    assert (tmp_path / "glushkov.dot").read_text().startswith("digraph") and (tmp_path / "thomson.dot").read_text().startswith("digraph")
 
 
 def test_cli_example_runner(tmp_path):

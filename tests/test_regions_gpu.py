@@ -111,6 +111,55 @@ def _fuzz_strings(rng, count, max_len):
     return out
 
 
+def test_long_region_behind_many_short_ones(monkeypatch):
+    """More candidates than the pass can hold (text made of a hundred medium runs) IN FRONT of a long periodic stretch: the pass
+    reads on and keeps the longest candidates, so the stretch is in the table (overflow flag set) and the walk jumps over it --
+    a prefix an attacker can build must not switch the acceleration off."""
+    import time
+    import torch
+    rng = np.random.default_rng(64)
+    strings = []
+    for q_word in (b"a", b"ab", b"aab", b"abbabba"):
+        head = b"".join(bytes([97 + (k % 2)]) * int(rng.integers(70, 130)) for k in range(100))      # ~100 runs of 70..130 bytes
+        strings.append(head + q_word * (60000 // len(q_word)) + b"c")
+    tabs = scan(strings)
+    check_tables(strings, tabs)
+    for s, row in zip(strings, tabs):
+        entries, overflow = decode(row)
+        assert overflow
+        longest = max(hi - lo for lo, hi, q in entries)
+        assert longest >= 59000, (longest, entries)
+    # and the walk uses it: example 1's automaton on a^n behind such a prefix must not take time proportional to n^2
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex1_plain"))
+    batch = [strings[0]] * 256
+    data, off = oracle_lib.pack(batch)
+    d_bytes = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+    d_bytes[:len(data)] = torch.from_numpy(data.copy())
+    d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+    for engine in ("table", "jit"):
+        monkeypatch.setenv("MFA_WALK", engine)
+        img = capi.Image(blob)
+        img.match_tensors(d_bytes, d_off)
+        got = img.match_tensors(d_bytes, d_off)
+        torch.cuda.synchronize()
+        assert img.last_kernel_ms(0) < 50.0, (engine, img.last_kernel_ms(0))      # every step executed: seconds
+        assert list(got.cpu().numpy()[:2]) == list(oracle_lib.OracleImage(blob).match(batch[:2]))
+
+
+def test_counted_waits_against_full_waits(monkeypatch):
+    """The row loop of the region pass waits with counted `s_waitcnt vmcnt(N)` that rely on the order of its requests; a build
+    that waits for everything (MFA_REGION_SAFE_WAITS=1) must produce the same tables on a large fuzz batch."""
+    rng = np.random.default_rng(777)
+    strings = _fuzz_strings(rng, 600, 9000) + _fuzz_strings(rng, 60, 70000)
+    fast = scan(strings, 3)
+    monkeypatch.setenv("MFA_REGION_SAFE_WAITS", "1")
+    safe = scan(strings, 3)
+    assert np.array_equal(fast[:, 0], safe[:, 0])
+    for k in range(len(strings)):
+        cnt = int(fast[k, 0]) & 0xff
+        assert np.array_equal(fast[k, :1 + cnt], safe[k, :1 + cnt]), k
+
+
 @pytest.mark.parametrize("pad", [0, 5, 15])
 def test_region_tables(pad):
     rng = np.random.default_rng(4242 + pad)
