@@ -47,7 +47,7 @@ extern "C" {
 /* limits of the device kernels (violations -> MFA_ERR_UNSUPPORTED at image creation) */
 #define MFA_MAX_NODES        1024u     /* MFA kind: nodes (any out-degree)                 */
 #define MFA_MAX_KERNEL_CELLS 9u        /* MFA kind: distinct memory cells ("1".."9", mfa.cpp:148) */
-#define MFA_MAX_DFA_STATES   4096u     /* NFA kind: reachable state sets after tabulation  */
+#define MFA_MAX_DFA_STATES   (1u << 20) /* NFA kind: reachable state sets after tabulation  */
 #define MFA_MAX_STRING_BYTES 0x00ffffffu /* 16 MiB - 1 per string                          */
 
 typedef struct mfa_image mfa_image_t;

@@ -4,6 +4,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "mfa_internal.h"
 
@@ -108,7 +109,10 @@ int device_prepare(mfa_image* img, int device, DeviceState** out) {
     if (h.h.kind == MFA_KIND_MFA) {
         if (img->walk_ok) rc = up((void**)&ds.d_walk, img->walk.words.data(), img->walk.words.size() * 4);
     } else {
-        rc = up((void**)&ds.d_dfa_trans, h.dfa_trans.data(), h.dfa_trans.size() * 2);
+        if (h.dfa_states <= 0xffffu) {
+            std::vector<uint16_t> t16(h.dfa_trans.begin(), h.dfa_trans.end());
+            rc = up((void**)&ds.d_dfa_trans, t16.data(), t16.size() * 2);
+        } else rc = up((void**)&ds.d_dfa_trans, h.dfa_trans.data(), h.dfa_trans.size() * 4);
         if (rc == MFA_OK) rc = up((void**)&ds.d_dfa_accept, h.dfa_accept.data(), h.dfa_accept.size());
         if (rc == MFA_OK) rc = up((void**)&ds.d_byte_class, h.byte_class, 256);
     }

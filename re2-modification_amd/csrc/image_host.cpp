@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <string>
+#include <unordered_map>
 
 #include "mfa_internal.h"
 
@@ -123,31 +125,45 @@ int tabulate_nfa(HostImage& img) {
     img.n_classes = (uint32_t)rep.size();
     if (img.n_classes > 255) return MFA_ERR_UNSUPPORTED;
 
+    // state sets as packed bit strings (up to MFA_MAX_DFA_STATES of them: determinisation can be exponential, e.g.
+    // (a|b)*a(a|b)^k has 2^(k+1) sets)
     Stepper st(img);
-    std::map<std::vector<uint8_t>, uint32_t> ids;
-    std::vector<std::vector<uint8_t>> sets;
-    std::vector<uint8_t> empty(n, 0), start(n, 0);
+    const size_t key_bytes = (n + 7) / 8;
+    auto pack = [&](const std::vector<uint8_t>& set) {
+        std::string k(key_bytes, '\0');
+        for (uint32_t v = 0; v < n; v++)
+            if (set[v]) k[v >> 3] = (char)(k[v >> 3] | (1 << (v & 7)));
+        return k;
+    };
+    auto unpack = [&](const std::string& k, std::vector<uint8_t>& set) {
+        for (uint32_t v = 0; v < n; v++) set[v] = (uint8_t)((k[v >> 3] >> (v & 7)) & 1);
+    };
+    std::unordered_map<std::string, uint32_t> ids;
+    std::vector<std::string> sets;
+    std::vector<uint8_t> empty(n, 0), start(n, 0), cur(n, 0);
     start[img.h.start] = 1;
-    ids[empty] = 0; sets.push_back(empty);
-    if (start != empty) { ids[start] = 1; sets.push_back(start); }
+    ids[pack(empty)] = 0; sets.push_back(pack(empty));
+    if (start != empty) { ids[pack(start)] = 1; sets.push_back(pack(start)); }
     img.dfa_trans.clear();
     for (size_t s = 0; s < sets.size(); s++) {
+        unpack(sets[s], cur);
         for (uint32_t c = 0; c < img.n_classes; c++) {
-            std::vector<uint8_t> t = s == 0 ? empty : st.step(sets[s], rep[c]);
+            const std::string t = pack(s == 0 ? empty : st.step(cur, rep[c]));
             auto it = ids.find(t);
             uint32_t id;
             if (it == ids.end()) {
                 id = (uint32_t)sets.size();
                 if (id >= MFA_MAX_DFA_STATES) return MFA_ERR_UNSUPPORTED;
-                ids[t] = id; sets.push_back(t);
+                ids.emplace(t, id); sets.push_back(t);
             } else id = it->second;
-            img.dfa_trans.push_back((uint16_t)id);
+            img.dfa_trans.push_back(id);
         }
     }
     img.dfa_states = (uint32_t)sets.size();
     img.dfa_accept.assign(img.dfa_states, 0);
     for (uint32_t s = 1; s < img.dfa_states; s++) {
-        std::vector<uint8_t> f = st.step(sets[s], -1);        // automata.cpp:201-202
+        unpack(sets[s], cur);
+        std::vector<uint8_t> f = st.step(cur, -1);            // automata.cpp:201-202
         img.dfa_accept[s] = f[img.h.finish];                  // automata.cpp:204-208
     }
     return MFA_OK;

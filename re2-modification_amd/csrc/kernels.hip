@@ -221,11 +221,12 @@ dfa_tiled_kernel(DfaPacked pk, const uint16_t* __restrict__ trans, const uint8_t
     }
 }
 
-// Tabulated automata whose table does not fit LDS (more than 127 state sets): the table stays in global memory -- a few
-// hundred KiB at most, resident in L2 -- and only the byte classes go to LDS.  One string per lane, 32-bit state.
-template <bool REV>
+// Tabulated automata whose table does not fit LDS (more than 127 state sets): the table stays in global memory -- resident in L2
+// up to a few MiB, 16-bit entries up to 65535 state sets and 32-bit entries beyond -- and only the byte classes go to LDS.  One
+// string per lane, 32-bit state.
+template <bool REV, class T>
 __global__ void __launch_bounds__(256)
-dfa_big_kernel(const uint16_t* __restrict__ trans, const uint8_t* __restrict__ accept_tab, const uint8_t* __restrict__ byte_class,
+dfa_big_kernel(const T* __restrict__ trans, const uint8_t* __restrict__ accept_tab, const uint8_t* __restrict__ byte_class,
                uint32_t n_classes, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
                uint8_t* __restrict__ results) {
     __shared__ uint8_t s_class[256];
@@ -283,7 +284,7 @@ static int launch_dfa_tiled(const HostImage& img, DeviceState& ds, LaunchCtx& cx
     auto kern = dfa_tiled_kernel<REV, PACKED, NLIT>;
     HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_start, s));
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, pk, ds.d_dfa_trans, ds.d_dfa_accept, ds.d_byte_class,
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, s, pk, (const uint16_t*)ds.d_dfa_trans, ds.d_dfa_accept, ds.d_byte_class,
                        img.dfa_states, img.n_classes, d_bytes, d_offsets, n, d_results);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_stop, s));
@@ -298,12 +299,20 @@ int launch_dfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const 
         if (blocks > cap) blocks = cap;
         if (blocks == 0) blocks = 1;
         HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_start, s));
+#define BIG_GO(REVV)                                                                                                                                         \
+    do {                                                                                                                                                     \
+        if (img.dfa_states <= 0xffffu)                                                                                                                       \
+            hipLaunchKernelGGL((dfa_big_kernel<REVV, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)ds.d_dfa_trans, ds.d_dfa_accept,  \
+                               ds.d_byte_class, img.n_classes, d_bytes, d_offsets, n, d_results);                                                            \
+        else                                                                                                                                                 \
+            hipLaunchKernelGGL((dfa_big_kernel<REVV, uint32_t>), dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)ds.d_dfa_trans, ds.d_dfa_accept,  \
+                               ds.d_byte_class, img.n_classes, d_bytes, d_offsets, n, d_results);                                                            \
+    } while (0)
         if (img.h.is_reversed)
-            hipLaunchKernelGGL(dfa_big_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, ds.d_dfa_trans, ds.d_dfa_accept, ds.d_byte_class,
-                               img.n_classes, d_bytes, d_offsets, n, d_results);
+            BIG_GO(true);
         else
-            hipLaunchKernelGGL(dfa_big_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, ds.d_dfa_trans, ds.d_dfa_accept, ds.d_byte_class,
-                               img.n_classes, d_bytes, d_offsets, n, d_results);
+            BIG_GO(false);
+#undef BIG_GO
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_stop, s));
         return MFA_OK;
@@ -341,11 +350,11 @@ int launch_dfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const 
     HIP_TRY(hipEventRecord((hipEvent_t)cx.ev_start, s));
     if (img.h.is_reversed) {
         HIP_TRY(hipFuncSetAttribute((const void*)dfa_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(dfa_walk_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, ds.d_dfa_trans, ds.d_dfa_accept,
+        hipLaunchKernelGGL(dfa_walk_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, s, (const uint16_t*)ds.d_dfa_trans, ds.d_dfa_accept,
                            ds.d_byte_class, img.dfa_states, img.n_classes, d_bytes, d_offsets, n, d_results);
     } else {
         HIP_TRY(hipFuncSetAttribute((const void*)dfa_walk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(dfa_walk_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, ds.d_dfa_trans, ds.d_dfa_accept,
+        hipLaunchKernelGGL(dfa_walk_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, s, (const uint16_t*)ds.d_dfa_trans, ds.d_dfa_accept,
                            ds.d_byte_class, img.dfa_states, img.n_classes, d_bytes, d_offsets, n, d_results);
     }
     HIP_TRY(hipGetLastError());

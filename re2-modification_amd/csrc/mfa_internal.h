@@ -28,7 +28,7 @@ struct HostImage {
     uint32_t              dfa_states = 0;
     uint32_t              n_classes  = 0;
     uint8_t               byte_class[256] = {0};
-    std::vector<uint16_t> dfa_trans;   // [dfa_states][n_classes]
+    std::vector<uint32_t> dfa_trans;   // [dfa_states][n_classes]
     std::vector<uint8_t>  dfa_accept;  // [dfa_states]: finish is in the set after the final pass
     mutable int           jit_source_ok = -1;      // MFA kind: the generated kernel's source is of a size a compiler finishes (jit.hip; -1 = not looked at)
 };
@@ -62,7 +62,7 @@ struct LaunchCtx {
 struct DeviceState {
     int       device = -1;
     // NFA kind
-    uint16_t* d_dfa_trans  = nullptr;
+    void*     d_dfa_trans  = nullptr;   // [dfa_states][n_classes], 16-bit entries up to 65535 state sets, 32-bit beyond
     uint8_t*  d_dfa_accept = nullptr;
     uint8_t*  d_byte_class = nullptr;
     // launch workspaces

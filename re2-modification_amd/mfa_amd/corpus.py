@@ -24,6 +24,19 @@ EXAMPLES = {
     10: ("({a*}:1b|b&1)*c&1", ["aababba"], "cab", ""),
 }
 
+# the reference's further examples (test/example_11..17: regexp.txt, pump.txt; no README row): not part of the benchmark corpus,
+# used by the tests
+MORE_EXAMPLES = {
+    11: ("({a*}:1b&1b)*", ["aa", "b", "aa"], "bbc", ""),
+    12: ("(({a*}:1b&1b)*)*", ["aa", "b", "aa"], "bbc", ""),
+    13: ("ba{aa*}:1a&1*", ["a", "a", "a"], "b", "ba"),
+    14: ("{(a*|b*)}:1b(&1|b)*", ["b", "b", "b", "b", "b"], "bc", ""),
+    15: ("{a*}:1c{a*}:2c(&1|&2)*", ["aa"], "b", "aacaac"),
+    16: ("({a*}:1&1|(a*|b)a)*", ["baaaa"], "b", ""),
+    17: ("(&1{a*}:1|(a*|b)a)*", ["baaaa"], "b", ""),
+}
+ALL_EXAMPLES = {**EXAMPLES, **MORE_EXAMPLES}
+
 
 def pumped_string(n, pump):
     """example_runner.cpp:15-29, host version (tests, small samples)."""
@@ -69,7 +82,7 @@ def layout(example, sizes, with_suffix):
 
 
 def host_strings(example, sizes, with_suffix):
-    regex, pump, suffix, prefix = EXAMPLES[example]
+    regex, pump, suffix, prefix = ALL_EXAMPLES[example]
     return [(prefix + pumped_string(int(n), pump) + (suffix if w else "")).encode() for n, w in zip(sizes, with_suffix)]
 
 

@@ -128,7 +128,7 @@ def test_cli_example_runner(tmp_path):
     from mfa_amd import corpus
     diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
     for ex in (1, 5):
-        regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+        regex, pump, suffix, prefix = corpus.ALL_EXAMPLES[ex]
         d = tmp_path / "test" / ("example_%d" % ex)
         d.mkdir(parents=True)
         (d / "regexp.txt").write_text(regex + "\nunused-python-regex\n")
@@ -161,7 +161,7 @@ def _structured_strings(ex, rng, count, max_len):
     """Attack-like inputs with long runs: pumped strings of random size with a few bytes flipped, and
     concatenations of runs -- what run acceleration jumps over."""
     from mfa_amd import corpus
-    regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+    regex, pump, suffix, prefix = corpus.ALL_EXAMPLES[ex]
     out = []
     for k in range(count):
         kind = k % 4
@@ -268,7 +268,7 @@ def test_full_length_attack_strings(ex):
     """BASELINE-size inputs (pump size 64 KiB, 40 000, 20 000 with a damaged byte) against the CPU
     restatement: the strings the benchmark is made of, at the lengths where run acceleration does most work."""
     from mfa_amd import corpus
-    regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+    regex, pump, suffix, prefix = corpus.ALL_EXAMPLES[ex]
     rng = np.random.default_rng(77 + ex)
     a = (prefix + corpus.pumped_string(65536, pump) + suffix).encode()
     b = (prefix + corpus.pumped_string(40000, pump)).encode()
@@ -493,13 +493,29 @@ def test_large_tabulated_automaton(tmp_path):
     assert np.array_equal(got, want) and 0 < want.sum() < len(strings)
 
 
+@pytest.mark.parametrize("k,flag", [(14, "-thompson"), (16, "-thompson"), (16, "-glushkov")])
+def test_exponential_tabulated_automaton(k, flag, tmp_path):
+    """(a|b)*a(a|b)^k: determinisation doubles with every k -- 32 770 state sets at k = 14 (16-bit table in L2), 131 074 at k = 16
+    (32-bit table) -- walked on the GPU against the CPU restatement, which walks the NFA itself (automata.cpp:177-210)."""
+    regex = "(a|b)*a" + "(a|b)" * k
+    blob = _front_end_blob(regex, tmp_path, flag)
+    img = capi.Image(blob)
+    assert img.info()["dfa_states"] > 4096
+    rng = np.random.default_rng(k)
+    strings = [bytes(rng.choice(list(b"ab"), size=int(n)).tolist()) for n in rng.integers(0, 400, size=500)]
+    strings += [b"", b"a" + b"b" * k, b"b" * (k + 1), b"ab" * 300 + b"a" + b"b" * k, b"ab" * 300 + b"b" + b"a" * k, b"abc" + b"a" * 30]
+    want = oracle_lib.OracleImage(blob).match(strings)
+    got = gpu_match(img, strings)
+    assert np.array_equal(got, want) and 0 < want.sum() < len(strings)
+
+
 @pytest.mark.parametrize("ex", [3, 6, 8])
 def test_full_length_reversed_strings(ex):
     """BASELINE configs[4] at its real size: the reversed automata (`-reverse`, is_reversed = 1) of the nondeterministic examples on
     pump-only strings (full walk) and pump + suffix strings (early exit) of pump size 64 KiB, 40 000 and 20 000 with a damaged
     byte, against the CPU restatement."""
     from mfa_amd import corpus
-    regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+    regex, pump, suffix, prefix = corpus.ALL_EXAMPLES[ex]
     rng = np.random.default_rng(170 + ex)
     a = (prefix + corpus.pumped_string(65536, pump)).encode()
     b = (prefix + corpus.pumped_string(65536, pump) + suffix).encode()
@@ -592,7 +608,7 @@ def test_long_strings_every_image(name, monkeypatch):
     (mfa.cpp:177-191).  Against the CPU restatement, on both engines."""
     from mfa_amd import corpus
     ex = int("".join(c for c in name.split("_")[0] if c.isdigit()))
-    regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+    regex, pump, suffix, prefix = corpus.ALL_EXAMPLES[ex]
     rng = np.random.default_rng(1000 + ex)
     strings = []
     for k in range(26):

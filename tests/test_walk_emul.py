@@ -35,14 +35,14 @@ def example_of(name):
     if not name.startswith("ex"):
         return None
     ex = int("".join(ch for ch in name.split("_")[0] if ch.isdigit()))
-    return ex if ex in corpus.EXAMPLES else None
+    return ex if ex in corpus.ALL_EXAMPLES else None
 
 
 def long_strings(name, rng):
     out = []
     ex = example_of(name)
     if ex is not None:
-        regex, pump, suffix, prefix = corpus.EXAMPLES[ex]
+        regex, pump, suffix, prefix = corpus.ALL_EXAMPLES[ex]
         for n in (70, 200, 700, 2500, 6000):
             for ws in (False, True):
                 s = (prefix + corpus.pumped_string(n, pump) + (suffix if ws else "")).encode()
