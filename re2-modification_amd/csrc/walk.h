@@ -23,7 +23,7 @@ struct WalkArgs {                     // kernel parameters; every pointer is a d
     uint32_t*       spill;            // per wave: list entries and probe images beyond the LDS capacity
     unsigned long long* counter;      // ticket counter, zeroed before the launch
     uint32_t table_words, shared_words;      // LDS words: the tables, and the tables rounded up to a multiple of 64
-    uint32_t n_seg, C, CX, accel;
+    uint32_t n_seg, C, CX, accel, refill;
     uint32_t seg_first[WALK_MAX_SEG + 1];    // segment s = strings seg_first[s] .. seg_first[s+1]-1 of this launch ...
     uint32_t seg_table[WALK_MAX_SEG];        // ... walks the automaton whose table block starts at this word of `tables`
 };

@@ -67,12 +67,13 @@ walk_kernel(WalkArgs a) {
     st.sa = base; base += a.C * DW * 64u;
     WALK_LDS uint64_t* const rtc = (WALK_LDS uint64_t*)base;
     const uint64_t gwave = (uint64_t)blockIdx.x * 4u + wave_u;
-    uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * (3u * W + 3u * DW));
+    uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * (3u * W + 3u * DW) + CMP_CACHE * 4u * 64u);
     st.gv = g; g += 2u * a.CX * W * 64u;
     st.gd = g; g += 2u * a.CX * DW * 64u;
     st.gsb = g; g += a.CX * W * 64u;
-    st.gsa = g;
-    Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.n_seg, a.seg_first, a.seg_table};
+    st.gsa = g; g += a.CX * DW * 64u;
+    st.gq = g;
+    Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.refill, a.n_seg, a.seg_first, a.seg_table};
     TicketFeeder feed{a.counter, a.n, gwave * 64u};
 #if WALK_STATS
     // development build: per-lane counts and per-wave cycle counts, added up in a.counter[8 ..]

@@ -32,6 +32,10 @@
 #define MFA_WALK_CORE_H
 
 #include "../../include/mfa_image_format.h"
+// the wave-wide scans of device_common.h with ONE block per lane in flight: their second block cost this kernel 10 registers at its
+// peak (the cell read sits in the innermost loop of the step) and bought no time
+#define MFA_SCAN_DEPTH 1
+#define MFA_RUN_DEPTH 1
 #include "device_common.h"
 
 #ifndef WALK_WV
@@ -85,9 +89,11 @@ inline bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, uin
 #define WALK_EV(k) ((void)0)
 WALK_DEV uint32_t wv_lane() { return threadIdx.x & 63u; }
 WALK_DEV uint64_t wv_shfl64(uint64_t v, int L) { return ((uint64_t)__shfl((uint32_t)(v >> 32), L) << 32) | __shfl((uint32_t)v, L); }
+// Out of line on purpose: a scan is rare (a run the region table does not hold, a long comparison outside known regions), sits in
+// the innermost loop of the step, and inlined it raised the kernel's register count by 25 for every wave, scanning or not.
 template <bool REV>
-WALK_DEV uint32_t coop_run_end_x(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t lane) { return coop_run_end<REV>(bytes, base, len, i0, lane); }
-WALK_DEV bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, uint32_t l, uint32_t lane) { return coop_mem_equal(bytes, pa, pb, l, lane); }
+__device__ __attribute__((noinline)) uint32_t coop_run_end_x(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t lane) { return coop_run_end<REV>(bytes, base, len, i0, lane); }
+__device__ __attribute__((noinline)) bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, uint32_t l, uint32_t lane) { return coop_mem_equal(bytes, pa, pb, l, lane); }
 #endif
 
 // ---- address spaces ------------------------------------------------------------------------------------------------------------
@@ -112,23 +118,25 @@ struct WIn {
     uint32_t len, sid;
     uint64_t blk;                // offset of the 16 bytes in w0..w3 (any alignment), MFA_NO_WINDOW = none
     uint32_t w0, w1, w2, w3;
-    uint64_t pblk;               // the window the lane expects to need next
-    uint32_t p0, p1, p2, p3;
     uint32_t run_lo, run_hi, run_ch;       // scan[run_lo, run_hi) == run_ch, maximal to the right
     uint32_t per_lo, per_hi, per_q;        // scan[j] == scan[j + per_q] for per_lo <= j < per_hi - per_q (0: none)
     uint32_t prev_lo, prev_hi, prev_q;     // the region known before that one
     uint32_t dual_p;                       // steps per period of the dual step in flight, 0 in plain steps
     uint32_t rt_cnt;                       // entries of this string's table row
+    // what the step could not decide without a wave-wide scan (the main loop scans between steps and runs the step again):
+    uint32_t rq;                           // 0 none, 1 the end of the run of byte rq_b at scan index rq_a, 2 scan[rq_a, +rq_l) == scan[rq_b, +rq_l)?
+    uint32_t rq_a, rq_b, rq_l;
+    uint32_t cq_n;                         // comparisons answered for the step being executed (Store::gq)
 };
 
-WALK_DEV void w_drop_window(WIn& in) { in.blk = MFA_NO_WINDOW; in.pblk = MFA_NO_WINDOW; }
+WALK_DEV void w_drop_window(WIn& in) { in.blk = MFA_NO_WINDOW; }
 WALK_DEV void w_reset(WIn& in, uint64_t base, uint32_t len, uint32_t sid) {
     in.base = base; in.len = len; in.sid = sid;
     w_drop_window(in);
     in.run_lo = in.run_hi = 0; in.run_ch = 0x100u;
     in.per_lo = in.per_hi = 0; in.per_q = 0; in.dual_p = 0;
     in.prev_lo = in.prev_hi = 0; in.prev_q = 0;
-    in.rt_cnt = 0;
+    in.rt_cnt = 0; in.rq = 0; in.rq_a = in.rq_b = in.rq_l = 0; in.cq_n = 0;
 }
 
 // The table row of the lane's string: header and first MFA_RT_CACHED entries arrive in (a, b) (two 16-byte loads that go out
@@ -196,29 +204,16 @@ template <bool REV> WALK_DEV uint64_t w_window_addr(const WIn& in, uint32_t j) {
     const uint64_t a = in.base + j;
     return a + 16u <= in.total16 ? a : in.total16 - 16u;
 }
-// every 16th iteration, all lanes: take the window asked for at the last turn, ask for the one after it (device_common.h, "the byte window")
-template <bool REV> WALK_DEV void w_window_turn(WIn& in, uint32_t i, bool reading) {
-    if (reading && w_scan_addr<REV>(in, i) - in.pblk < 16u) { in.w0 = in.p0; in.w1 = in.p1; in.w2 = in.p2; in.w3 = in.p3; in.blk = in.pblk; }
-    in.pblk = MFA_NO_WINDOW;
-    if (reading && i + 16u < in.len) {
-        const uint64_t b = w_window_addr<REV>(in, i + 16u);
-        const uint4 d = load16u(in.bytes, b);
-        in.p0 = d.x; in.p1 = d.y; in.p2 = d.z; in.p3 = d.w; in.pblk = b;
-    }
-}
-// the byte at scan index i (i < len); to_turn = iterations until the next window turn, this one included (1..16)
-template <bool REV> WALK_DEV uint32_t w_stream_byte(WIn& in, uint32_t i, uint32_t to_turn) {
+// the byte at scan index i (i < len).  A lane keeps 16 bytes of its string in registers (any alignment); it loads the next 16
+// when it runs off them, or lands somewhere else after a jump: one load per 16 steps, waited for on the spot (a step of this
+// kernel is several microseconds: a second window requested ahead, as the generated kernels keep one, bought nothing here and
+// cost five registers)
+template <bool REV> WALK_DEV uint32_t w_stream_byte(WIn& in, uint32_t i) {
     const uint64_t addr = w_scan_addr<REV>(in, i);
     uint64_t o = addr - in.blk;
-    if (o >= 16u) {                                      // a string begins, or a jump has landed here
+    if (o >= 16u) {
         const uint64_t a = w_window_addr<REV>(in, i);
         const uint4 d = load16u(in.bytes, a);
-        in.pblk = MFA_NO_WINDOW;
-        if (i + to_turn < in.len) {                      // where the lane will be at the next turn if it walks on step by step
-            const uint64_t b = w_window_addr<REV>(in, i + to_turn);
-            const uint4 e = load16u(in.bytes, b);
-            in.p0 = e.x; in.p1 = e.y; in.p2 = e.z; in.p3 = e.w; in.pblk = b;
-        }
         in.w0 = d.x; in.w1 = d.y; in.w2 = d.z; in.w3 = d.w; in.blk = a;
         o = addr - a;
     }
@@ -316,16 +311,24 @@ WALK_DEV bool w_read_pre(WIn& in, U i, uint32_t ch, U start, U l, uint32_t fl, t
 }
 
 // ---- per-lane view of an automaton's tables ------------------------------------------------------------------------------------
-struct Aut {
-    uint32_t cmap, vinfo, vc, vb, ee;      // word offsets into the table block
-    uint32_t nc, vbits, start;
+struct Aut {                 // three registers per lane: where the automaton's table block starts, and its two dimensions
+    uint32_t at, nv, dims;   // dims = classes | variant bits << 8
+    WALK_DEV uint32_t nc() const { return dims & 0xffu; }
+    WALK_DEV uint32_t vbits() const { return dims >> 8; }
+    // the block's layout is fixed (walk_tables.cpp): header, class map, vinfo[nv], vc[nv], vb[nv][nc], effective edges
+    WALK_DEV uint32_t cmap() const { return at + 16u; }
+    WALK_DEV uint32_t vinfo() const { return at + 80u; }
+    WALK_DEV uint32_t vc() const { return at + 80u + nv; }
+    WALK_DEV uint32_t vb() const { return at + 80u + 2u * nv; }
+    WALK_DEV uint32_t ee() const { return at + 80u + nv * (2u + nc()); }
 };
 template <class TP> WALK_DEV void aut_load(Aut& a, TP T, uint32_t at) {
-    a.cmap = at + T[at + 5]; a.vinfo = at + T[at + 6]; a.vc = at + T[at + 7]; a.vb = at + T[at + 8]; a.ee = at + T[at + 9];
-    a.nc = T[at + 2]; a.vbits = T[at + 1]; a.start = T[at + 4];
+    a.at = at; a.nv = T[at]; a.dims = T[at + 2] | (T[at + 1] << 8);
 }
+template <class TP> WALK_DEV uint32_t aut_start(TP T, const Aut& a) { return T[a.at + 4]; }
 
 // ---- list storage -----------------------------------------------------------------------------------------------------------------
+constexpr uint32_t CMP_CACHE = 4;      // answered comparisons a lane can hold for one step (beyond them it compares by itself)
 template <int K> struct Lay {
     static constexpr uint32_t W = 2 + 2 * K;            // value words per entry
     static constexpr uint32_t DW = (1 + 2 * K + 1) / 2;  // direction words per entry: int16 each (pos, then S, L per cell)
@@ -341,6 +344,7 @@ struct Store {               // wave-uniform bases; every access adds the lane
     uint32_t* gd;            // global [2][CX][DW][WV]
     uint32_t* gsb;           // global [CX][W][WV]
     uint32_t* gsa;           // global [CX][DW][WV]
+    uint32_t* gq;            // global [CMP_CACHE][4][WV]  long comparisons answered for the step in progress: a, b, l, equal
     uint32_t C, CX;
 };
 
@@ -503,39 +507,141 @@ WALK_DEV void apply_actions(Ent<U, K>& t, uint32_t actions, bool pred, U ts, U t
 
 // ---- a cell read (mfa.cpp:177-191) on the lanes in `rd`: does scan[i, i + |v|) equal the value? ----------------------------------------
 // Run extents and byte-wise comparisons are done by the whole wave, one lane's at a time (device_common.h).
-template <bool REV, class U>
-WALK_DEV bool cell_read(WIn& in, bool rd, U i, uint32_t ch, U vs, U vl, uint32_t vf, tb_t& TB) {
+
+// The exclusive end of the run of byte ch that contains scan index i, for the lanes in `nr`: from the region table (q = 1 entries are
+// maximal runs), else measured -- a short stretch lane by lane, the rest by the whole wave.  Out of line on purpose: it is needed when
+// a lane enters a new run (not every step), sits in the innermost loop of the step, and inlined it raised the kernel's register count
+// by 25 for every wave.  scanned: the end comes from a measurement (the caller then also knows a periodic region).
+struct RunEnd { uint32_t end; bool scanned; };
+#ifdef MFA_HOST_EMUL
+template <bool REV> inline
+#else
+template <bool REV> __device__ __attribute__((noinline))
+#endif
+RunEnd run_end_for(const uint8_t* bytes, uint64_t total16, const uint64_t* regions, WALK_LDS uint64_t* rtc, uint64_t base, uint32_t len, uint32_t sid,
+                   uint32_t rt_cnt, bool nr, uint32_t i, uint32_t ch) {
+    WIn in;
+    in.bytes = bytes; in.total16 = total16; in.regions = regions; in.rtc = rtc; in.base = base; in.len = len; in.sid = sid; in.rt_cnt = rt_cnt;
+    RunEnd out{0u, false};
     const uint32_t lane = wv_lane();
-    {
-        bool nr = rd && w_uni_needs_run(in, val(i), ch, val(vl), vf);
-        if (nr && in.regions != nullptr) {                    // the region pass knows every long run
-            uint32_t rh;
-            if (w_rt_run<REV>(in, val(i), rh) || w_run_end_bounded<REV>(in, val(i), ch, 192u, rh)) { in.run_lo = val(i); in.run_hi = rh; in.run_ch = ch; nr = false; }
-        }
-        for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {
-            const int L = __builtin_ctzll(sb);
-            const uint32_t r = coop_run_end_x<REV>(in.bytes, wv_shfl64(in.base, L), __shfl(in.len, L), __shfl(val(i), L), lane);
-            if (lane == (uint32_t)L) {
-                in.run_lo = val(i); in.run_hi = r; in.run_ch = ch;
-                // a run is a periodic region too (unless one that reaches at least as far is known: a probe may rely on it)
-                if (!(in.per_q != 0u && in.per_lo <= val(i) && val(i) < in.per_hi && in.per_hi >= r)) { in.per_lo = val(i); in.per_hi = r; in.per_q = 1u; }
-            }
-        }
+    if (nr && regions != nullptr) {
+        uint32_t rh;
+        if (w_rt_run<REV>(in, i, rh) || w_run_end_bounded<REV>(in, i, ch, 192u, rh)) { out.end = rh; nr = false; }
+    }
+    for (unsigned long long sb = __ballot(nr); sb; sb &= sb - 1ull) {
+        const int L = __builtin_ctzll(sb);
+        const uint32_t r = coop_run_end_x<REV>(bytes, wv_shfl64(base, L), __shfl(len, L), __shfl(i, L), lane);
+        if (lane == (uint32_t)L) { out.end = r; out.scanned = true; }
+    }
+    return out;
+}
+
+// The end of the run of byte ch at scan index i, if the 16 bytes the lane holds show it (no load): most short runs do end there.
+template <bool REV> WALK_DEV bool w_run_end_in_window(const WIn& in, uint32_t i, uint32_t ch, uint32_t& end) {
+    const uint64_t o64 = w_scan_addr<REV>(in, i) - in.blk;
+    if (o64 >= 16u) return false;
+    const uint32_t o = (uint32_t)o64;
+    const uint32_t m = mismatch_mask16(make_uint4(in.w0, in.w1, in.w2, in.w3), ch);      // bit k: byte k of the window is not ch
+    if (!REV) {
+        const uint32_t after = m >> (o + 1u);                      // scan indices i+1, i+2, ... = window bytes o+1, o+2, ...
+        if (after) { const uint32_t e = i + 1u + (uint32_t)__builtin_ctz(after); end = e < in.len ? e : in.len; return true; }
+        if (i + (16u - o) >= in.len) { end = in.len; return true; }      // the window reaches the end of the string
+        return false;
+    }
+    const uint32_t below = m & ((1u << o) - 1u);                   // scan indices i+1, i+2, ... = window bytes o-1, o-2, ...
+    if (below) { const uint32_t e = i + (o - (31u - (uint32_t)__builtin_clz(below))); end = e < in.len ? e : in.len; return true; }
+    if (i + 1u + o >= in.len) { end = in.len; return true; }
+    return false;
+}
+// ... or the 16 bytes behind them (one load: runs of up to 17-32 bytes; longer ones are asked for, see cell_read)
+template <bool REV> WALK_DEV bool w_run_end_next_block(const WIn& in, uint32_t i, uint32_t ch, uint32_t& end) {
+    const uint64_t o64 = w_scan_addr<REV>(in, i) - in.blk;
+    if (o64 >= 16u) return false;
+    const uint32_t o = (uint32_t)o64;
+    if (!REV) {
+        const uint64_t a2 = in.blk + 16u;
+        if (a2 + 16u > in.total16) return false;
+        const uint32_t m = mismatch_mask16(load16u(in.bytes, a2), ch), first = i + (16u - o);      // scan index of the block's byte 0
+        if (m) { const uint32_t e = first + (uint32_t)__builtin_ctz(m); end = e < in.len ? e : in.len; return true; }
+        if (first + 16u >= in.len) { end = in.len; return true; }
+        return false;
+    }
+    if (in.blk < 16u) return false;
+    const uint32_t m = mismatch_mask16(load16u(in.bytes, in.blk - 16u), ch);                        // byte k = scan index i + o + 16 - k
+    if (m) { const uint32_t e = i + o + 16u - (31u - (uint32_t)__builtin_clz(m)); end = e < in.len ? e : in.len; return true; }
+    if (i + o + 17u >= in.len) { end = in.len; return true; }
+    return false;
+}
+
+// The step itself scans nothing: a read that needs the end of a run the lane does not know, or a byte-wise comparison of long
+// spans, leaves a REQUEST in the lane's input state and counts as failed; the main loop answers the requests between steps (with
+// the whole wave, at a point where few registers are live) and executes the step again -- the step is a function of the list, the
+// byte and what the lane knows, so the second execution is the real one.  (Inlined into the step, the scans raised the kernel's
+// register count by 25-40 for every wave, scanning or not.)
+template <bool REV, class U>
+WALK_DEV bool cell_read(const Store& st, WIn& in, bool rd, U i, uint32_t ch, U vs, U vl, uint32_t vf, tb_t& TB) {
+    bool nr = rd && w_uni_needs_run(in, val(i), ch, val(vl), vf);
+    if (nr) {
+        uint32_t e;
+        if (w_run_end_in_window<REV>(in, val(i), ch, e) || w_run_end_next_block<REV>(in, val(i), ch, e)) { in.run_lo = val(i); in.run_hi = e; in.run_ch = ch; nr = false; }
+        else if (in.rq == 0u) { in.rq = 1u; in.rq_a = val(i); in.rq_b = ch; }
     }
     bool ok = false, cmp = false;
-    if (rd) ok = w_read_pre<REV, U>(in, i, ch, vs, vl, vf, TB, cmp);
-    for (unsigned long long sb = __ballot(cmp); sb; sb &= sb - 1ull) {
-        const int L = __builtin_ctzll(sb);
-        const uint32_t ca = val(vs), cb = val(i), cl = val(vl);
-        const uint64_t pa = in.base + (REV ? (uint64_t)(in.len - ca - cl) : (uint64_t)ca), pb = in.base + (REV ? (uint64_t)(in.len - cb - cl) : (uint64_t)cb);
-        const bool r = coop_mem_equal_x(in.bytes, wv_shfl64(pa, L), wv_shfl64(pb, L), __shfl(cl, L), lane);
-        if (lane == (uint32_t)L) ok = r;
+    if (rd && !nr) ok = w_read_pre<REV, U>(in, i, ch, vs, vl, vf, TB, cmp);
+    if (__any(cmp)) {
+        if (cmp) {
+            const uint32_t ca = val(vs), cb = val(i), cl = val(vl);
+            bool known = false;
+            for (uint32_t k = 0; k < in.cq_n; k++) {
+                uint32_t* q = st.gq + (size_t)(k * 4u) * WALK_WV + wv_lane();
+                if (q[0] == ca && q[WALK_WV] == cb && q[2 * WALK_WV] == cl) { ok = q[3 * WALK_WV] != 0u; known = true; }
+            }
+            if (!known) {
+                if (in.cq_n >= CMP_CACHE) ok = w_spans_equal<REV>(in, ca, cb, cl);      // (more long comparisons in one step than a lane can hold: by itself)
+                else if (in.rq == 0u) { in.rq = 2u; in.rq_a = ca; in.rq_b = cb; in.rq_l = cl; }
+            }
+        }
     }
     return ok;
 }
 
+// the requests of the wave's lanes, answered by the whole wave (main loop, between two executions of a step)
+template <bool REV>
+WALK_DEV void answer_requests(const Store& st, WIn& in, bool active) {
+    const uint32_t lane = wv_lane();
+    {
+        const bool nr = active && in.rq == 1u;
+        if (__any(nr)) {
+            const RunEnd re = run_end_for<REV>(in.bytes, in.total16, in.regions, in.rtc, in.base, in.len, in.sid, in.rt_cnt, nr, in.rq_a, in.rq_b);
+            if (nr) {
+                in.run_lo = in.rq_a; in.run_hi = re.end; in.run_ch = in.rq_b;
+                // a measured run is a periodic region too (unless one that reaches at least as far is known: a probe may rely on it)
+                if (re.scanned && !(in.per_q != 0u && in.per_lo <= in.rq_a && in.rq_a < in.per_hi && in.per_hi >= re.end)) { in.per_lo = in.rq_a; in.per_hi = re.end; in.per_q = 1u; }
+            }
+        }
+    }
+    const bool cm = active && in.rq == 2u;
+    for (unsigned long long sb = __ballot(cm); sb; sb &= sb - 1ull) {
+        const int L = __builtin_ctzll(sb);
+        const uint64_t pa = in.base + (REV ? (uint64_t)(in.len - in.rq_a - in.rq_l) : (uint64_t)in.rq_a), pb = in.base + (REV ? (uint64_t)(in.len - in.rq_b - in.rq_l) : (uint64_t)in.rq_b);
+        const bool r = coop_mem_equal_x(in.bytes, wv_shfl64(pa, L), wv_shfl64(pb, L), __shfl(in.rq_l, L), lane);
+        if (lane == (uint32_t)L) {
+            uint32_t* q = st.gq + (size_t)(in.cq_n * 4u) * WALK_WV + lane;
+            q[0] = in.rq_a; q[WALK_WV] = in.rq_b; q[2 * WALK_WV] = in.rq_l; q[3 * WALK_WV] = r ? 1u : 0u;
+            in.cq_n++;
+        }
+    }
+    in.rq = 0u;
+}
+
 // ---- the step --------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t KEYS = 4;      // entries of the list being built whose keys are also kept in registers
+constexpr uint32_t KEYS = 4;      // entries of the list being built whose keys are also kept in registers (plain steps)
+template <class U> struct KeyCache;
+template <> struct KeyCache<uint32_t> {
+    static constexpr uint32_t N = KEYS;
+    uint32_t id[KEYS], P[KEYS];      // node | tie << 16 and P of the first KEYS entries: a candidate for one of them is decided without reading the list
+};
+template <> struct KeyCache<Dual> { static constexpr uint32_t N = 0; uint32_t id[1], P[1]; };      // dual steps are rare: they search the list
 template <class U, int K>
 struct StepCtx {
     const Store& st;
@@ -544,8 +650,7 @@ struct StepCtx {
     bool dual_lane;          // per lane: directions are meaningful
     bool fits;               // per lane: every direction stored so far fits 16 bits
     tb_t TB;
-    // the first KEYS entries' node | tie << 16 and P: a candidate for one of them is decided without reading the list
-    uint32_t k_id[KEYS], k_P[KEYS];
+    KeyCache<U> keys;
 };
 
 // candidate (P, tie, cells of t) for the node of `vid` on the lanes in `pred`
@@ -555,11 +660,12 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
     if (pred) WALK_EV(2);
     uint32_t at = ~0u, old_tie = 0u;
     U old = konst<U>(0u);
+    constexpr uint32_t NK = KeyCache<U>::N;
 #pragma unroll
-    for (uint32_t k = 0; k < KEYS; k++)
-        if (pred && k < cx.n_next && (cx.k_id[k] & 0xffffu) == node) { at = k; old_tie = cx.k_id[k] >> 16; setv(old, cx.k_P[k]); }
-    if (__any(pred && at == ~0u && cx.n_next > KEYS)) {        // longer lists: look through the rest
-        for (uint32_t j = KEYS; __any(pred && at == ~0u && j < cx.n_next); j++) {
+    for (uint32_t k = 0; k < NK; k++)
+        if (pred && k < cx.n_next && (cx.keys.id[k] & 0xffffu) == node) { at = k; old_tie = cx.keys.id[k] >> 16; setv(old, cx.keys.P[k]); }
+    if (__any(pred && at == ~0u && cx.n_next > NK)) {          // longer lists: look through the rest
+        for (uint32_t j = NK; __any(pred && at == ~0u && j < cx.n_next); j++) {
             WALK_EV(3);
             const bool look = pred && at == ~0u && j < cx.n_next;
             const uint32_t x = look ? rd_v<K>(cx.st, cx.nxt, j, 1) : 0u;
@@ -576,8 +682,8 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
         t.P = P; t.vid = vid;
         store_entry<U, K>(cx.st, cx.nxt, at, t, tie, cx.fits);
 #pragma unroll
-        for (uint32_t k = 0; k < KEYS; k++)
-            if (at == k) { cx.k_id[k] = node | (tie << 16); cx.k_P[k] = val(P); }
+        for (uint32_t k = 0; k < NK; k++)
+            if (at == k) { cx.keys.id[k] = node | (tie << 16); cx.keys.P[k] = val(P); }
     }
 }
 
@@ -615,8 +721,8 @@ template <class U, int K, bool REV, class TP>
 WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uint32_t cur, uint32_t n_cur, uint32_t& n_next,
                         const U i, const U len, const uint32_t ch, const bool final_pass, const bool active, const bool dual_lane,
                         bool& accept, bool& fits, tb_t& TB) {
-    StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
-    const uint32_t cls = (active && !final_pass) ? (T[au.cmap + ((ch & 0xffu) >> 2)] >> (8u * (ch & 3u))) & 0xffu : 0u;
+    StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB, {}};
+    const uint32_t cls = (active && !final_pass) ? (T[au.cmap() + ((ch & 0xffu) >> 2)] >> (8u * (ch & 3u))) & 0xffu : 0u;
     for (uint32_t e = 0; __any(active && e < n_cur); e++) {
         const bool have = active && e < n_cur;
         if (have) WALK_EV(0);
@@ -635,43 +741,44 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
         }
         const bool here = live && !final_pass && eq(pos, i, cx.TB);
         const bool wait = live && !final_pass && !here;
-        const uint32_t vi = have ? T[au.vinfo + E.vid] : 0u;
-        const uint32_t node = E.vid >> au.vbits;
+        const uint32_t vi = have ? T[au.vinfo() + E.vid] : 0u;
+        const uint32_t node = E.vid >> au.vbits();
         // an epsilon edge: the state reaches `finish`, which keeps it iff pos == len (mfa.cpp:138-147); accepting is sticky
         if ((vi & VI_EPS) && live && !accept && eq(pos, len, cx.TB)) accept = true;
         {   // a waiting state goes back into the set as it is (mfa.cpp:195-197): older than everything created in this step
             const bool carry = wait && (vi & VI_QUAL) != 0u;
-            if (__any(carry)) { Ent<U, K> t = E; insert<U, K>(cx, carry, E.vid, au.vbits, E.P, TIE_CARRY, t); }
+            if (__any(carry)) { Ent<U, K> t = E; insert<U, K>(cx, carry, E.vid, au.vbits(), E.P, TIE_CARRY, t); }
         }
         // ---- the state at pos == i consumes (mfa.cpp:161-194)
         if (__any(here)) {
-            const uint32_t bl = here ? T[au.vb + E.vid * au.nc + cls] : 0u;
+            const uint32_t bl = here ? T[au.vb() + E.vid * au.nc() + cls] : 0u;
             const uint32_t bbeg = bl >> 12, bcnt = bl & 0xfffu;
             for (uint32_t j = 0; __any(j < bcnt); j++) {
                 const bool p = here && j < bcnt;
                 if (p) WALK_EV(1);
                 uint32_t e0, actions, cm, com, rdm;
-                ee_decode<K, TP>(T, au.ee + (bbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
+                ee_decode<K, TP>(T, au.ee() + (bbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
                 const uint32_t tvid = e0 >> 9, tfn = (e0 >> 5) & 15u, cell = (e0 >> 1) & 15u;
-                Ent<U, K> s = E;                                     // (most edges start from the entry's own cells)
-                if (__any(p && (cm | rdm) != 0u)) frame_state<U, K>(E, pos, cm, com, rdm, s);
+                // the state the edge starts from = the candidate before the edge's actions: the entry's cells (most edges), or those
+                // plus the cells created on the way and the marks of earlier reads.  The copy is taken before read() marks the source
+                // (mfa.cpp:167 / 177): the edge's own mark is not in rdm.
+                Ent<U, K> t = E;
+                if (__any(p && (cm | rdm) != 0u)) frame_state<U, K>(E, pos, cm, com, rdm, t);
                 const bool lit = p && (e0 & 1u) == 0u, rd = p && (e0 & 1u) != 0u;
                 if (__any(lit)) {                                    // a letter (or dot) edge takes the byte (mfa.cpp:171-175)
-                    Ent<U, K> t = s;
                     apply_actions<U, K>(t, actions, lit, i, konst<U>(1u), true, ch, cx.TB);
-                    insert<U, K>(cx, lit, tvid, au.vbits, mkp(add(i, konst<U>(1u)), tfn), TIE_HERE + node, t);
+                    insert<U, K>(cx, lit, tvid, au.vbits(), mkp(add(i, konst<U>(1u)), tfn), TIE_HERE + node, t);
                 }
                 if (__any(rd)) {                                     // a cell edge reads the cell's value (mfa.cpp:176-191)
-                    Ent<U, K> t = s;                                 // the copy is taken before read() marks the source (mfa.cpp:167 / 177)
                     U vs = konst<U>(0u), vl = konst<U>(0u);
                     uint32_t vf = 0u;
 #pragma unroll
                     for (int c = 0; c < K; c++)
-                        if ((uint32_t)c == cell) { vs = s.S[c]; vl = s.L[c]; vf = s.F[c]; }
-                    const bool ok = cell_read<REV, U>(in, rd, i, ch, vs, vl, vf, cx.TB);
+                        if ((uint32_t)c == cell) { vs = t.S[c]; vl = t.L[c]; vf = t.F[c]; }
+                    const bool ok = cell_read<REV, U>(st, in, rd, i, ch, vs, vl, vf, cx.TB);
                     if (__any(ok)) {
                         apply_actions<U, K>(t, actions, ok, i, vl, (vf & F_UNI) != 0u, (vf >> 8) & 0xffu, cx.TB);
-                        insert<U, K>(cx, ok, tvid, au.vbits, mkp(add(i, vl), tfn), TIE_HERE + node, t);
+                        insert<U, K>(cx, ok, tvid, au.vbits(), mkp(add(i, vl), tfn), TIE_HERE + node, t);
                     }
                 }
             }
@@ -680,16 +787,16 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
         const bool late = live && !here;
         if ((vi & VI_CACC) && late && !accept && eq(pos, len, cx.TB)) accept = true;
         if (__any(wait && (vi & VI_HASC) != 0u)) {
-            const uint32_t cl = (wait && (vi & VI_HASC) != 0u) ? T[au.vc + E.vid] : 0u;
+            const uint32_t cl = (wait && (vi & VI_HASC) != 0u) ? T[au.vc() + E.vid] : 0u;
             const uint32_t cbeg = cl >> 12, ccnt = cl & 0xfffu;
             for (uint32_t j = 0; __any(j < ccnt); j++) {
                 const bool p = wait && j < ccnt;
                 if (p) WALK_EV(6);
                 uint32_t e0, actions, cm, com, rdm;
-                ee_decode<K, TP>(T, au.ee + (cbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
+                ee_decode<K, TP>(T, au.ee() + (cbeg + j) * Lay<K>::EEW, p, e0, actions, cm, com, rdm);
                 Ent<U, K> t;
                 frame_state<U, K>(E, pos, cm, com, 0u, t);
-                insert<U, K>(cx, p, e0 >> 9, au.vbits, mkp(pos, (e0 >> 5) & 15u), TIE_WAIT + node, t);
+                insert<U, K>(cx, p, e0 >> 9, au.vbits(), mkp(pos, (e0 >> 5) & 15u), TIE_WAIT + node, t);
             }
         }
     }
@@ -813,6 +920,7 @@ struct Batch {
     uint8_t* results;
     const uint64_t* regions;     // region table (regions.hip) or nullptr
     uint32_t accel;
+    uint32_t refill;             // idle lanes of a wave that make it fetch new strings (1: every lane at once when it runs out)
     uint32_t n_seg;              // segments of the batch: strings seg_first[s] .. seg_first[s+1]-1 belong to the automaton whose tables
     const uint32_t* seg_first;   //   start at word seg_table[s] of the table block (n_seg + 1 / n_seg entries, 32-bit string indices)
     const uint32_t* seg_table;
@@ -838,14 +946,14 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
     WIn in;
     in.bytes = b.bytes; in.total16 = (b.offsets[b.n] + 15u) & ~(uint64_t)15; in.regions = b.regions; in.rtc = rt_cache;
     w_reset(in, 0, 0, 0);
-    in.w0 = in.w1 = in.w2 = in.w3 = in.p0 = in.p1 = in.p2 = in.p3 = 0;
+    in.w0 = in.w1 = in.w2 = in.w3 = 0;
     bool active = false, exhausted = false, accept = false;
     uint32_t i = 0, len = 0; uint64_t sid = 0;
     // probes: phase 0 idle, 1 = plain periods after saving the list, 2 = the dual period
     uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1, nper = 0;
     tb_t TBacc = tb_init();
     bool fits = true, stable = false, patient = false;
-    uint32_t cur = 0, n_cur = 0, sb_n = 0, warm = 0, turn = 0;
+    uint32_t cur = 0, n_cur = 0, sb_n = 0, warm = 0;
     Aut au;
     aut_load(au, T, 0u);
     const unsigned long long tm_begin = stats ? wv_clock() : 0ull;
@@ -853,8 +961,11 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
         unsigned long long tm = stats ? wv_clock() : 0ull;
 #define WALK_LAP(field) do { if (stats) { const unsigned long long now_ = wv_clock(); stats->field += now_ - tm; tm = now_; } } while (0)
         {   // hand strings to idle lanes
+            // Idle lanes take new strings together: a string's start is three dependent trips to memory (ticket, offsets, first
+            // bytes) that the whole wave waits for, so it is paid once per `refill` lanes, not once per lane that runs out
             const bool want = !active && !exhausted;
-            if (__any(want)) {
+            const unsigned long long wantb = __ballot(want);
+            if (wantb && ((uint32_t)__builtin_popcountll(wantb) >= b.refill || !__any(active))) {
                 uint64_t s = 0;
                 const bool got = feed.take(want, s);
                 if (want) {
@@ -877,7 +988,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                             stable = false; patient = false;
                             n_cur = 1;                                // the list: (pos 0, start, no cells)  mfa.cpp:217-219
                             Ent<uint32_t, K> e0;
-                            e0.P = 0u; e0.vid = au.start;
+                            e0.P = 0u; e0.vid = aut_start(T, au);
 #pragma unroll
                             for (int c = 0; c < K; c++) { e0.S[c] = 0u; e0.L[c] = 0u; e0.F[c] = 0u; }
                             bool f2 = true;
@@ -892,9 +1003,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
         WALK_LAP(t_start);
         const bool final_pass = (i == len);
         uint32_t ch = 0x100u;
-        if (turn == 0u) w_window_turn<REV>(in, i, active && !final_pass);      // the byte windows of all lanes are renewed together
-        if (active && !final_pass) ch = w_stream_byte<REV>(in, i, 16u - turn);
-        turn = (turn + 1u) & 15u;
+        if (active && !final_pass) ch = w_stream_byte<REV>(in, i);
         WALK_LAP(t_byte);
         // ---- does this lane sit at the start of a stretch that repeats?  (probes run in epochs: all lanes that probe do it together)
         uint32_t q = 0u;
@@ -929,20 +1038,27 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
         uint32_t n_next = 0;
         tb_t TB = tb_init();
         const bool p2 = phase == 2u;
-        if (WALK_WITH_DUAL && __any(p2)) {
-            // dual step: lanes in their dual period carry the list's directions, the others direction 0 (their TB is ignored)
-            if (stats) stats->dual++;
-            const Dual di{i, (int32_t)pp}, dlen{len, 0};
-            in.dual_p = p2 ? pp : 0u;
-            (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the region
-            (void)eq(di, dlen, TB);
-            walk_step<Dual, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB);
-            in.dual_p = 0u;
-            WALK_LAP(t_dual);
-        } else {
-            bool f2 = true;
-            walk_step<uint32_t, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB);
-            WALK_LAP(t_plain);
+        const bool accept_before = accept, fits_before = fits;
+        in.cq_n = 0u;
+        for (;;) {                                                   // (again after the wave has answered what the step asked for)
+            n_next = 0; TB = tb_init(); accept = accept_before; fits = fits_before;
+            if (WALK_WITH_DUAL && __any(p2)) {
+                // dual step: lanes in their dual period carry the list's directions, the others direction 0 (their TB is ignored)
+                if (stats) stats->dual++;
+                const Dual di{i, (int32_t)pp}, dlen{len, 0};
+                in.dual_p = p2 ? pp : 0u;
+                (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the region
+                (void)eq(di, dlen, TB);
+                walk_step<Dual, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB);
+                in.dual_p = 0u;
+                WALK_LAP(t_dual);
+            } else {
+                bool f2 = true;
+                walk_step<uint32_t, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB);
+                WALK_LAP(t_plain);
+            }
+            if (!__any(active && in.rq != 0u)) break;
+            answer_requests<REV>(st, in, active);
         }
         cur ^= 1u;
         if (active) n_cur = n_next;

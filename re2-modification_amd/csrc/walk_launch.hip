@@ -58,6 +58,7 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     for (uint32_t k = 0; k < n_seg; k++) a.seg_table[k] = seg_table[k];
     const char* ae = getenv("MFA_ACCEL");
     a.accel = (ae && ae[0] == '0') ? 0u : 1u;
+    a.refill = (uint32_t)std::max(1, std::min(64, env_int("MFA_WALK_REFILL", 1)));
     // capacity
     const size_t lds_max = 160u * 1024u / 4u;                 // words
     const int want_c = env_int("MFA_WALK_C", 0);
@@ -81,7 +82,7 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     L.grid = (unsigned)grid;
     L.reversed = p.reversed;
     const uint32_t W = 2 + 2 * p.K, DW = (1 + 2 * p.K + 1) / 2;
-    const size_t need = (size_t)grid * 4u * a.CX * 64u * (3u * W + 3u * DW) * sizeof(uint32_t);
+    const size_t need = (size_t)grid * 4u * ((size_t)a.CX * 64u * (3u * W + 3u * DW) + 4u * 4u * 64u) * sizeof(uint32_t);      // + the comparison answers (walk_core.h: CMP_CACHE)
     int rc = ctx_reserve((void**)d_spill, spill_bytes, need);
     if (rc != MFA_OK) return rc;
     a.spill = *d_spill;

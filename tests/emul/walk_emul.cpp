@@ -79,9 +79,9 @@ template <int K, bool REV>
 static void run(const Batch& b, const std::vector<uint32_t>& T, uint32_t C, uint32_t CM, WaveStats* ws) {
     const uint32_t CX = CM > C ? CM - C : 1u;
     std::vector<uint32_t> lv(2 * C * Lay<K>::W, 0xdeadbeefu), ld(2 * C * Lay<K>::DW, 0xdeadbeefu), sb(C * Lay<K>::W, 0xdeadbeefu), sa(C * Lay<K>::DW, 0xdeadbeefu),
-        gv(2 * CX * Lay<K>::W, 0xdeadbeefu), gd(2 * CX * Lay<K>::DW, 0xdeadbeefu), gsb(CX * Lay<K>::W, 0xdeadbeefu), gsa(CX * Lay<K>::DW, 0xdeadbeefu);
+        gv(2 * CX * Lay<K>::W, 0xdeadbeefu), gd(2 * CX * Lay<K>::DW, 0xdeadbeefu), gsb(CX * Lay<K>::W, 0xdeadbeefu), gsa(CX * Lay<K>::DW, 0xdeadbeefu), gq(CMP_CACHE * 4, 0xdeadbeefu);
     Store st;
-    st.lv = lv.data(); st.ld = ld.data(); st.sb = sb.data(); st.sa = sa.data(); st.gv = gv.data(); st.gd = gd.data(); st.gsb = gsb.data(); st.gsa = gsa.data(); st.C = C; st.CX = CX;
+    st.lv = lv.data(); st.ld = ld.data(); st.sb = sb.data(); st.sa = sa.data(); st.gv = gv.data(); st.gd = gd.data(); st.gsb = gsb.data(); st.gsa = gsa.data(); st.gq = gq.data(); st.C = C; st.CX = CX;
     uint64_t rtc[MFA_RT_CACHED] = {0};
     SeqFeeder feed;
     feed.n = b.n;
@@ -133,7 +133,7 @@ int main(int argc, char** argv) {
         table.resize(n * MFA_REGION_WORDS);
         for (uint64_t k = 0; k < n; k++) region_row(bytes.data() + off[k], (uint32_t)(off[k + 1] - off[k]), &table[k * MFA_REGION_WORDS]);
     }
-    Batch b{bytes.data(), off.data(), n, res.data(), accel ? table.data() : nullptr, (uint32_t)(accel != 0), (uint32_t)seg_table.size(), seg_first.data(), seg_table.data()};
+    Batch b{bytes.data(), off.data(), n, res.data(), accel ? table.data() : nullptr, (uint32_t)(accel != 0), 1u, (uint32_t)seg_table.size(), seg_first.data(), seg_table.data()};
     WaveStats ws;
     if (n) {
 #define GO(KK) do { if (rev) run<KK, true>(b, T, C, CM, &ws); else run<KK, false>(b, T, C, CM, &ws); } while (0)

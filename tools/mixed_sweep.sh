@@ -1,6 +1,3 @@
-export SKIP_PER_EX=1
-for ws in 1 2 3; do
-  echo "== table, walk streams $ws"
-  MFA_MIXED_WALK_STREAMS=$ws ENGINES=table timeout -k 10 200 python tools/walk_check.py timing 2>&1 | grep "^mixed"
-done
-echo "== jit"; ENGINES=jit timeout -k 10 200 python tools/walk_check.py timing 2>&1 | grep "^mixed"
+export ENGINES=table CUTS="0.3,0.6,0.8,0.9" SKIP_PER_EX=1
+timeout -k 10 300 python tools/walk_check.py timing 2>&1 | grep -E "^mixed|^ex"
+timeout -k 10 300 python tools/walk_bench.py table rev8 nonper 2>&1 | grep -v amdgpu
