@@ -24,6 +24,7 @@ struct WalkArgs {                     // kernel parameters; every pointer is a d
     unsigned long long* counter;      // ticket counter, zeroed before the launch
     uint32_t table_words, shared_words;      // LDS words: the tables, and the tables rounded up to a multiple of 64
     uint32_t n_seg, C, CX, accel, refill;
+    uint32_t images_global;           // the two probe images of a lane live in global memory (less LDS per wave: more waves per CU)
     uint32_t seg_first[WALK_MAX_SEG + 1];    // segment s = strings seg_first[s] .. seg_first[s+1]-1 of this launch ...
     uint32_t seg_table[WALK_MAX_SEG];        // ... walks the automaton whose table block starts at this word of `tables`
 };
@@ -35,7 +36,7 @@ struct WalkLaunch {
     bool     tables_global;           // the tables do not fit LDS: the kernel reads them from global memory (shared_words = 0)
 };
 
-#define MFA_WALK_DECL(K) int launch_walk_k##K(const WalkLaunch& L, void* stream); size_t walk_wave_words_k##K(uint32_t C);
+#define MFA_WALK_DECL(K) int launch_walk_k##K(const WalkLaunch& L, void* stream); size_t walk_wave_words_k##K(uint32_t C, bool images_global);
 MFA_WALK_DECL(1) MFA_WALK_DECL(2) MFA_WALK_DECL(3) MFA_WALK_DECL(4) MFA_WALK_DECL(5) MFA_WALK_DECL(6) MFA_WALK_DECL(7) MFA_WALK_DECL(8) MFA_WALK_DECL(9)
 #undef MFA_WALK_DECL
 int launch_walk_stats(const WalkLaunch& L, void* stream);      // K = 1 with counters (MFA_WALK_STATS=1; development)

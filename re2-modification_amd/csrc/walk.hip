@@ -55,23 +55,24 @@ walk_kernel(WalkArgs a) {
         __syncthreads();
     }
     constexpr uint32_t W = Lay<K>::W, DW = Lay<K>::DW;
-    const uint32_t per_wave = a.C * 64u * (3u * W + 3u * DW) + 2u * 64u * MFA_RT_CACHED;
+    const uint32_t CI = a.images_global ? 0u : a.C, XI = a.CX + a.C - CI;      // image entries in LDS / in global memory
+    const uint32_t per_wave = a.C * 64u * (2u * W + 2u * DW) + CI * 64u * (W + DW) + 2u * 64u * MFA_RT_CACHED;
     // the wave's number as a scalar: everything derived from it stays in scalar registers
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     WALK_LDS uint32_t* base = (WALK_LDS uint32_t*)smem + a.shared_words + wave_u * per_wave;
     Store st;
-    st.C = a.C; st.CX = a.CX;
+    st.C = a.C; st.CX = a.CX; st.CI = CI;
     st.lv = base; base += 2u * a.C * W * 64u;
     st.ld = base; base += 2u * a.C * DW * 64u;
-    st.sb = base; base += a.C * W * 64u;
-    st.sa = base; base += a.C * DW * 64u;
+    st.sb = base; base += CI * W * 64u;
+    st.sa = base; base += CI * DW * 64u;
     WALK_LDS uint64_t* const rtc = (WALK_LDS uint64_t*)base;
     const uint64_t gwave = (uint64_t)blockIdx.x * 4u + wave_u;
-    uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * (3u * W + 3u * DW) + CMP_CACHE * 4u * 64u);
+    uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * (2u * W + 2u * DW) + (uint64_t)XI * 64u * (W + DW) + CMP_CACHE * 4u * 64u);
     st.gv = g; g += 2u * a.CX * W * 64u;
     st.gd = g; g += 2u * a.CX * DW * 64u;
-    st.gsb = g; g += a.CX * W * 64u;
-    st.gsa = g; g += a.CX * DW * 64u;
+    st.gsb = g; g += XI * W * 64u;
+    st.gsa = g; g += XI * DW * 64u;
     st.gq = g;
     Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.refill, a.n_seg, a.seg_first, a.seg_table};
     TicketFeeder feed{a.counter, a.n, gwave * 64u};
@@ -98,7 +99,9 @@ walk_kernel(WalkArgs a) {
 #define WALK_CAT(a, b) WALK_CAT2(a, b)
 
 // words of LDS one wave needs at capacity C
-static size_t wave_words(uint32_t C) { return (size_t)C * 64u * (3u * Lay<WALK_K>::W + 3u * Lay<WALK_K>::DW) + 2u * 64u * MFA_RT_CACHED; }
+static size_t wave_words(uint32_t C, bool images_global) {
+    return (size_t)C * 64u * ((images_global ? 2u : 3u) * (Lay<WALK_K>::W + Lay<WALK_K>::DW)) + 2u * 64u * MFA_RT_CACHED;
+}
 
 #if WALK_STATS
 int launch_walk_stats(const WalkLaunch& L, void* stream) {
@@ -107,7 +110,7 @@ int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
 #endif
     WalkArgs a = L.args;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = ((size_t)a.shared_words + 4u * wave_words(a.C)) * 4u;
+    const size_t lds = ((size_t)a.shared_words + 4u * wave_words(a.C, a.images_global != 0u)) * 4u;
     if (lds > 160u * 1024u) return MFA_ERR_UNSUPPORTED;
     hipError_t e = hipSuccess;
 #define WALK_GO(REVV, TGV)                                                                                                                   \
@@ -124,7 +127,7 @@ int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
 }
 
 #if !WALK_STATS
-size_t WALK_CAT(walk_wave_words_k, WALK_K)(uint32_t C) { return wave_words(C); }
+size_t WALK_CAT(walk_wave_words_k, WALK_K)(uint32_t C, bool images_global) { return wave_words(C, images_global); }
 #endif
 
 }  // namespace mfa

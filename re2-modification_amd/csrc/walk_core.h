@@ -346,6 +346,7 @@ struct Store {               // wave-uniform bases; every access adds the lane
     uint32_t* gsa;           // global [CX][DW][WV]
     uint32_t* gq;            // global [CMP_CACHE][4][WV]  long comparisons answered for the step in progress: a, b, l, equal
     uint32_t C, CX;
+    uint32_t CI;             // entries of the two probe images that are in LDS (C, or 0: the images live in global memory)
 };
 
 // single words (the images of a probe use them: rare)
@@ -635,13 +636,15 @@ WALK_DEV void answer_requests(const Store& st, WIn& in, bool active) {
 }
 
 // ---- the step --------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t KEYS = 4;      // entries of the list being built whose keys are also kept in registers (plain steps)
+constexpr uint32_t KEYS = 4;      // entries of the list being built whose keys are also kept in registers (plain steps; eight of them cost
+                                  // four more registers at the kernel's peak: one region wave fewer beside two walk waves)
 template <class U> struct KeyCache;
 template <> struct KeyCache<uint32_t> {
     static constexpr uint32_t N = KEYS;
     uint32_t id[KEYS], P[KEYS];      // node | tie << 16 and P of the first KEYS entries: a candidate for one of them is decided without reading the list
+    unsigned long long seen;         // bit (node & 63): some entry of the list has such a node -- a clear bit spares the search behind the keys
 };
-template <> struct KeyCache<Dual> { static constexpr uint32_t N = 0; uint32_t id[1], P[1]; };      // dual steps are rare: they search the list
+template <> struct KeyCache<Dual> { static constexpr uint32_t N = 0; uint32_t id[1], P[1]; unsigned long long seen; };      // dual steps are rare: they search the list
 template <class U, int K>
 struct StepCtx {
     const Store& st;
@@ -662,12 +665,18 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
     U old = konst<U>(0u);
     constexpr uint32_t NK = KeyCache<U>::N;
 #pragma unroll
-    for (uint32_t k = 0; k < NK; k++)
+    for (uint32_t k = 0; k < (NK < 4u ? NK : 4u); k++)
         if (pred && k < cx.n_next && (cx.keys.id[k] & 0xffffu) == node) { at = k; old_tie = cx.keys.id[k] >> 16; setv(old, cx.keys.P[k]); }
-    if (__any(pred && at == ~0u && cx.n_next > NK)) {          // longer lists: look through the rest
-        for (uint32_t j = NK; __any(pred && at == ~0u && j < cx.n_next); j++) {
+    if (NK > 4u && __any(pred && at == ~0u && cx.n_next > 4u)) {      // (lists of the README automata never get here)
+#pragma unroll
+        for (uint32_t k = 4; k < NK; k++)
+            if (pred && k < cx.n_next && (cx.keys.id[k] & 0xffffu) == node) { at = k; old_tie = cx.keys.id[k] >> 16; setv(old, cx.keys.P[k]); }
+    }
+    const bool maybe = NK == 0u || ((cx.keys.seen >> (node & 63u)) & 1ull) != 0ull;
+    if (__any(pred && maybe && at == ~0u && cx.n_next > NK)) {          // longer lists: look through the rest
+        for (uint32_t j = NK; __any(pred && maybe && at == ~0u && j < cx.n_next); j++) {
             WALK_EV(3);
-            const bool look = pred && at == ~0u && j < cx.n_next;
+            const bool look = pred && maybe && at == ~0u && j < cx.n_next;
             const uint32_t x = look ? rd_v<K>(cx.st, cx.nxt, j, 1) : 0u;
             if (look && ((x & 0xffffu) >> vbits) == node) { at = j; old_tie = x >> 16; setv(old, rd_v<K>(cx.st, cx.nxt, j, 0)); }
         }
@@ -678,7 +687,7 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
         win = lt(P, old, cx.TB) || (eq(P, old, cx.TB) && tie < old_tie);
     }
     if (win) {
-        if (at == ~0u) at = cx.n_next++;
+        if (at == ~0u) { at = cx.n_next++; cx.keys.seen |= 1ull << (node & 63u); }
         t.P = P; t.vid = vid;
         store_entry<U, K>(cx.st, cx.nxt, at, t, tie, cx.fits);
 #pragma unroll
@@ -722,6 +731,7 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
                         const U i, const U len, const uint32_t ch, const bool final_pass, const bool active, const bool dual_lane,
                         bool& accept, bool& fits, tb_t& TB) {
     StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB, {}};
+    cx.keys.seen = 0ull;
     const uint32_t cls = (active && !final_pass) ? (T[au.cmap() + ((ch & 0xffu) >> 2)] >> (8u * (ch & 3u))) & 0xffu : 0u;
     for (uint32_t e = 0; __any(active && e < n_cur); e++) {
         const bool have = active && e < n_cur;
@@ -804,13 +814,13 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
 }
 
 // ---- the list one period ago (SB) and its movement (SA) ----------------------------------------------------------------------------------
-template <int K> WALK_DEV uint32_t sb_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.C ? st.sb[(e * Lay<K>::W + w) * WALK_WV + wv_lane()] : st.gsb[((e - st.C) * Lay<K>::W + w) * WALK_WV + wv_lane()]; }
+template <int K> WALK_DEV uint32_t sb_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.CI ? st.sb[(e * Lay<K>::W + w) * WALK_WV + wv_lane()] : st.gsb[((e - st.CI) * Lay<K>::W + w) * WALK_WV + wv_lane()]; }
 template <int K> WALK_DEV void sb_wr(const Store& st, uint32_t e, uint32_t w, uint32_t v) {
-    if (e < st.C) st.sb[(e * Lay<K>::W + w) * WALK_WV + wv_lane()] = v; else st.gsb[((e - st.C) * Lay<K>::W + w) * WALK_WV + wv_lane()] = v;
+    if (e < st.CI) st.sb[(e * Lay<K>::W + w) * WALK_WV + wv_lane()] = v; else st.gsb[((e - st.CI) * Lay<K>::W + w) * WALK_WV + wv_lane()] = v;
 }
-template <int K> WALK_DEV uint32_t sa_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.C ? st.sa[(e * Lay<K>::DW + w) * WALK_WV + wv_lane()] : st.gsa[((e - st.C) * Lay<K>::DW + w) * WALK_WV + wv_lane()]; }
+template <int K> WALK_DEV uint32_t sa_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.CI ? st.sa[(e * Lay<K>::DW + w) * WALK_WV + wv_lane()] : st.gsa[((e - st.CI) * Lay<K>::DW + w) * WALK_WV + wv_lane()]; }
 template <int K> WALK_DEV void sa_wr(const Store& st, uint32_t e, uint32_t w, uint32_t v) {
-    if (e < st.C) st.sa[(e * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v; else st.gsa[((e - st.C) * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v;
+    if (e < st.CI) st.sa[(e * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v; else st.gsa[((e - st.CI) * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v;
 }
 
 // index of a value word's direction: 0 = P (in units of 16), 1 + 2c = S of cell c, 2 + 2c = L of cell c; word 1 has none

@@ -28,11 +28,11 @@ int walk_mode() {
     return !e ? 0 : e[0] == 't' ? 1 : e[0] == 'j' ? 2 : 0;     // "table" / "jit"; anything else: automatic
 }
 
-static size_t wave_words(uint32_t K, uint32_t C) {
+static size_t wave_words(uint32_t K, uint32_t C, bool ig) {
     switch (K) {
-        case 1: return walk_wave_words_k1(C); case 2: return walk_wave_words_k2(C); case 3: return walk_wave_words_k3(C);
-        case 4: return walk_wave_words_k4(C); case 5: return walk_wave_words_k5(C); case 6: return walk_wave_words_k6(C);
-        case 7: return walk_wave_words_k7(C); case 8: return walk_wave_words_k8(C); default: return walk_wave_words_k9(C);
+        case 1: return walk_wave_words_k1(C, ig); case 2: return walk_wave_words_k2(C, ig); case 3: return walk_wave_words_k3(C, ig);
+        case 4: return walk_wave_words_k4(C, ig); case 5: return walk_wave_words_k5(C, ig); case 6: return walk_wave_words_k6(C, ig);
+        case 7: return walk_wave_words_k7(C, ig); case 8: return walk_wave_words_k8(C, ig); default: return walk_wave_words_k9(C, ig);
     }
 }
 
@@ -60,18 +60,20 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     a.accel = (ae && ae[0] == '0') ? 0u : 1u;
     a.refill = (uint32_t)std::max(1, std::min(64, env_int("MFA_WALK_REFILL", 1)));
     // capacity
+    const bool ig = env_int("MFA_WALK_IMAGES_GLOBAL", 0) != 0;
+    a.images_global = ig ? 1u : 0u;
     const size_t lds_max = 160u * 1024u / 4u;                 // words
     const int want_c = env_int("MFA_WALK_C", 0);
     const uint32_t c_cap = want_c > 0 ? (uint32_t)want_c : 8u;
     uint32_t C = std::min(p.max_live, c_cap);
     if (C < 1) C = 1;
     const uint32_t wgs_goal = (uint32_t)env_int("MFA_WALK_WGS", 2);
-    while (C > 1 && want_c <= 0 && a.shared_words + 4u * wave_words(p.K, C) > lds_max / wgs_goal) C--;
-    while (C > 1 && a.shared_words + 4u * wave_words(p.K, C) > lds_max) C--;
-    if (a.shared_words + 4u * wave_words(p.K, C) > lds_max) return MFA_ERR_UNSUPPORTED;      // the tables alone fill the LDS
+    while (C > 1 && want_c <= 0 && a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max / wgs_goal) C--;
+    while (C > 1 && a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max) C--;
+    if (a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max) return MFA_ERR_UNSUPPORTED;      // the tables alone fill the LDS
     a.C = C;
     a.CX = p.max_live > C ? p.max_live - C : 1u;
-    const size_t lds_words = a.shared_words + 4u * wave_words(p.K, C);
+    const size_t lds_words = a.shared_words + 4u * wave_words(p.K, C, ig);
     uint64_t per_cu = lds_max / lds_words;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
@@ -82,7 +84,7 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     L.grid = (unsigned)grid;
     L.reversed = p.reversed;
     const uint32_t W = 2 + 2 * p.K, DW = (1 + 2 * p.K + 1) / 2;
-    const size_t need = (size_t)grid * 4u * ((size_t)a.CX * 64u * (3u * W + 3u * DW) + 4u * 4u * 64u) * sizeof(uint32_t);      // + the comparison answers (walk_core.h: CMP_CACHE)
+    const size_t need = (size_t)grid * 4u * ((size_t)(a.CX + a.C) * 64u * (3u * W + 3u * DW) + 4u * 4u * 64u) * sizeof(uint32_t);      // + the comparison answers (walk_core.h: CMP_CACHE)
     int rc = ctx_reserve((void**)d_spill, spill_bytes, need);
     if (rc != MFA_OK) return rc;
     a.spill = *d_spill;
