@@ -144,6 +144,9 @@ void mfa_mixed_destroy(mfa_mixed_t* mx);
  * seg_first[s] .. seg_first[s+1]-1 are matched against images[s].  Device pointers as in mfa_match_batch. */
 int  mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                      const uint64_t* seg_first, uint8_t* d_results, int device, void* stream);
+/* the same with HOST pointers (copy in, match, copy out, synchronise): for callers that hold std::strings */
+int  mfa_match_mixed_host(mfa_mixed_t* mx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
+                          const uint64_t* seg_first, uint8_t* results, int device);
 /* device time of the last mfa_match_mixed call on `device`: its region launches, and first region launch to
  * last walk (either pointer may be NULL).  Synchronises on the call's last events. */
 int  mfa_mixed_last_ms(mfa_mixed_t* mx, int device, float* region_ms, float* span_ms);

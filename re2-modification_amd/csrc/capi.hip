@@ -214,6 +214,11 @@ static int match_impl(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* 
     const bool jit = want_jit && jit_load(img->host, *ds);
     const bool table_walk = is_mfa && !jit && img->walk_ok;
     if (is_mfa && !jit && !table_walk) return MFA_ERR_JIT;      // only a generated kernel could walk it, and none could be built
+    // MFA_REQUIRE_JIT=1: a caller that counts on the specialised kernel's step rate gets an error instead of the other engine;
+    // MFA_VERBOSE=1: which kernel walks, on stderr
+    if (is_mfa && !jit) { const char* rq = getenv("MFA_REQUIRE_JIT"); if (rq && rq[0] == '1') return MFA_ERR_JIT; }
+    if (const char* vb = getenv("MFA_VERBOSE"))
+        if (vb[0] == '1') fprintf(stderr, "mfa_hip: %s\n", !is_mfa ? "table walk of the tabulated automaton (dfa_*_kernel)" : jit ? "kernel generated for this automaton (mfa_jit_kernel)" : "table-driven walk (walk_kernel)");
     LaunchCtx* cx = nullptr;
     rc = ctx_acquire(*ds, stream, &cx);
     if (rc != MFA_OK) return rc;

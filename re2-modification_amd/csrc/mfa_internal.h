@@ -98,7 +98,7 @@ namespace mfa {
 int launch_dfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const uint8_t* d_bytes, const uint64_t* d_offsets,
                     uint64_t n, uint8_t* d_results, void* stream);
 // regions.hip
-int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream);
+int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream, unsigned threads = 256);
 // launch contexts (capi.hip); the caller holds the image mutex
 int  ctx_acquire(DeviceState& ds, void* stream, LaunchCtx** out);
 int  ctx_reserve(void** buf, size_t* have, size_t need);

@@ -452,14 +452,16 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
     }
 }
 
-int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream) {
+int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream, unsigned threads) {
     if (n == 0) return MFA_OK;
     hipStream_t s = (hipStream_t)stream;
     const char* em = getenv("MFA_REGION_MODE");                   // development knobs
     const int mode = em ? atoi(em) : 0;
     const uint64_t cus = (uint64_t)(n_cus > 0 ? n_cus : 256);
     const char* eb = getenv("MFA_REGION_BLOCK");                  // development: threads per workgroup (64, 128 or 256)
-    const unsigned block = eb && (atoi(eb) == 64 || atoi(eb) == 128) ? (unsigned)atoi(eb) : 256u;
+    // 256 threads when the pass runs alone (its tuned form); 128 when walk kernels run beside it (mfa_match_mixed): workgroups of two
+    // waves find room on SIMDs that walk waves share, and the pass loses less to them (3.80 against 3.92 ms per headline step)
+    const unsigned block = eb && (atoi(eb) == 64 || atoi(eb) == 128 || atoi(eb) == 256) ? (unsigned)atoi(eb) : (threads == 128u ? 128u : 256u);
     const uint64_t wpb = block / 64u;
     uint64_t blocks = (n + wpb - 1) / wpb;
     const uint64_t cap = cus * 8u * 64u * (4u / wpb);             // beyond this waves take several strings each

@@ -125,7 +125,7 @@ using namespace mfa;
 //   * generated kernels (default while they are the faster walk on small automata): one launch per segment, spread over a few walk
 //     streams by measured cost -- the first call on a device runs the walks one after the other and times them, later calls give
 //     each walk to the stream that can start it first (list scheduling with the groups' region times as release times).
-constexpr uint32_t MIX_MAX_GROUPS = 8, MIX_MAX_STREAMS = 4, MIX_MAX_LAUNCHES = 24;
+constexpr uint32_t MIX_MAX_GROUPS = 12, MIX_MAX_STREAMS = 4, MIX_MAX_LAUNCHES = 24;
 
 struct mfa_mixed {
     std::vector<mfa_image*> images;
@@ -256,7 +256,7 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
     std::vector<uint64_t> cut{0};
     {
         const char* spec = getenv("MFA_MIXED_CUTS");
-        if (!spec) spec = n >= 65536 ? "0.3,0.6,0.8,0.9" : "";
+        if (!spec) spec = n < 65536 ? "" : table ? "0.15,0.3,0.45,0.6,0.75,0.87,0.95" : "0.3,0.6,0.8,0.9";
         for (const char* q = spec; *q && cut.size() < MIX_MAX_GROUPS;) {
             const uint64_t at = (uint64_t)((double)n * atof(q));
             if (at > cut.back() && at < n) cut.push_back(at);
@@ -300,7 +300,7 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
     for (uint32_t g = 0; g < ng; g++) {
         const uint64_t lo = cut[g], hi = cut[g + 1];
         if (with_regions) {
-            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d->d_regions + lo * MFA_REGION_WORDS, d->rs);
+            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d->d_regions + lo * MFA_REGION_WORDS, d->rs, table ? 128u : 256u);
             if (rc != MFA_OK) return rc;
         }
         HIP_TRY(hipEventRecord(d->ev_g[g], d->rs));
@@ -378,6 +378,41 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
         d->calibrated = true;
     }
     return MFA_OK;
+}
+
+// The same with HOST pointers: copies the batch to the device, matches, copies the results back, synchronises (the host mirror's
+// match_mixed and the `diploma -match-mixed` command line; throughput is then bounded by the host link).
+int mfa_match_mixed_host(mfa_mixed_t* mx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n, const uint64_t* seg_first, uint8_t* results, int device) {
+    if (!mx || !offsets || !seg_first || (!results && n)) return MFA_ERR_INVALID_ARG;
+    if (n == 0) return MFA_OK;
+    for (uint64_t k = 0; k < n; k++) {
+        if (offsets[k + 1] < offsets[k]) return MFA_ERR_INVALID_ARG;
+        if (offsets[k + 1] - offsets[k] > MFA_MAX_STRING_BYTES) return MFA_ERR_TOO_LONG;
+    }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return MFA_ERR_NO_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    const uint64_t total = offsets[n] - offsets[0];
+    uint8_t* d_bytes = nullptr; uint64_t* d_off = nullptr; uint8_t* d_res = nullptr;
+    std::vector<uint64_t> rel(n + 1);
+    for (uint64_t k = 0; k <= n; k++) rel[k] = offsets[k] - offsets[0];
+    int rc = MFA_OK;
+    hipError_t e = hipMalloc((void**)&d_bytes, total + 64);
+    if (e == hipSuccess) e = hipMalloc((void**)&d_off, (n + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void**)&d_res, n);
+    if (e == hipSuccess && total) e = hipMemcpy(d_bytes, bytes + offsets[0], total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_off, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }
+    if (rc == MFA_OK) rc = mfa_match_mixed(mx, d_bytes, d_off, n, seg_first, d_res, device, nullptr);
+    if (rc == MFA_OK) {
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipMemcpy(results, d_res, n, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }
+    }
+    if (d_bytes) (void)hipFree(d_bytes);
+    if (d_off) (void)hipFree(d_off);
+    if (d_res) (void)hipFree(d_res);
+    return rc;
 }
 
 // Device time of the last mfa_match_mixed on `device`: from its first region launch to the end of its last region launch, and to

@@ -244,4 +244,28 @@ void MFA::match_packed(const uint8_t* bytes, const uint64_t* offsets, uint64_t n
 
 vector<bool> MFA::match_batch(const vector<string>& strs) { return Automata::match_batch(strs); }
 
+vector<vector<bool>> match_mixed(const vector<MFA*>& automata, const vector<vector<string>>& strs) {
+    if (automata.empty() || automata.size() != strs.size()) throw std::runtime_error("match_mixed: one list of strings per automaton");
+    vector<mfa_image_t*> images;
+    for (MFA* m : automata) images.push_back(m->image_for_match());
+    mfa_mixed_t* mx = nullptr;
+    int rc = mfa_mixed_create(images.data(), (uint32_t)images.size(), &mx);
+    if (rc != MFA_OK) fail("mfa_mixed_create", rc);
+    vector<uint64_t> off{0}, seg{0};
+    vector<uint8_t> bytes;
+    for (const auto& list : strs) {
+        for (const string& s : list) { bytes.insert(bytes.end(), s.begin(), s.end()); off.push_back(bytes.size()); }
+        seg.push_back(off.size() - 1);
+    }
+    bytes.resize(bytes.size() + 16);
+    const uint64_t n = off.size() - 1;
+    vector<uint8_t> res(n + 1);
+    rc = mfa_match_mixed_host(mx, bytes.data(), off.data(), n, seg.data(), res.data(), automata[0]->device);
+    mfa_mixed_destroy(mx);
+    if (rc != MFA_OK) fail("mfa_match_mixed_host", rc);
+    vector<vector<bool>> out;
+    for (size_t k = 0; k < strs.size(); k++) out.emplace_back(res.begin() + seg[k], res.begin() + seg[k + 1]);
+    return out;
+}
+
 bool MFA::match(string str) { return Automata::match(str); }

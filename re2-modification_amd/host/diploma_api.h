@@ -114,6 +114,9 @@ public:
 #define Memory map<string, Variable*>
 #define MemoryState pair<int, pair<MemoryNode*, Memory>>
 
+class MFA;
+vector<vector<bool>> match_mixed(const vector<MFA*>& automata, const vector<vector<string>>& strs);
+
 class Automata {
 public:
     Node* start;
@@ -142,6 +145,7 @@ public:
     int device = 0;    // HIP device the match calls run on
 
 protected:
+    friend vector<vector<bool>> match_mixed(const vector<MFA*>& automata, const vector<vector<string>>& strs);
     mfa_image* image_for_match();
     mfa_image* cached_image_ = nullptr;
     vector<uint8_t> cached_blob_;
@@ -304,6 +308,9 @@ std::string substr(std::string originalString, int maxLength);
 void match(string regexp_str, bool reverse, bool bnf, bool ssnf, bool use_log = false);
 // matchers/match_mfa.cpp:13,58 counterparts: strings from a file (one per line), one batch, results and
 // timing on stdout
+// several automata, one batch: strs[k] are matched against automata[k] (memory automata only) by ONE device call
+// (mfa_match_mixed: the region pre-pass and the walks of all of them scheduled together); results[k][j] = automata[k] matches strs[k][j]
+vector<vector<bool>> match_mixed(const vector<MFA*>& automata, const vector<vector<string>>& strs);
 void match_gt(string regexp_str, const string& input_path = "input_strings.txt");
 void match_mfa(string regexp_str, const string& input_path = "mfa_str.txt");
 

@@ -5,6 +5,7 @@
 //   diploma -match-file <gt|mfa> <file>                       matchers/match_mfa.cpp counterparts
 #include <algorithm>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <sstream>
 
@@ -78,6 +79,29 @@ int do_dump(int argc, char** argv) {
 int main(int argc, char* argv[]) {
     try {
         if (argc > 1 && std::strcmp(argv[1], "-dump") == 0) return do_dump(argc, argv);
+        if (argc > 2 && std::strcmp(argv[1], "-match-mixed") == 0) {
+            // diploma -match-mixed FILE...: every file holds a regex (line 1) and strings (one per line); all of them are matched by
+            // ONE device call; prints the 0/1 lines of file 1, then of file 2, ...
+            vector<MFA*> automata;
+            vector<vector<string>> strs;
+            std::ostringstream sink;
+            for (int a = 2; a < argc; a++) {
+                std::ifstream f(argv[a]);
+                if (!f.is_open()) { cout << "ERROR\n"; return 1; }
+                string regex, line;
+                std::getline(f, regex);
+                std::streambuf* old = cout.rdbuf(sink.rdbuf());      // compile() prints its header lines
+                Regexp* re = Regexp::parse_regexp(regex);
+                re->is_backref_correct();
+                automata.push_back(re->to_binary_tree()->toMFA());
+                cout.rdbuf(old);
+                strs.emplace_back();
+                while (std::getline(f, line)) strs.back().push_back(line);
+            }
+            for (const auto& r : match_mixed(automata, strs))
+                for (bool b : r) cout << (b ? 1 : 0) << "\n";
+            return 0;
+        }
         if (argc > 3 && std::strcmp(argv[1], "-match-file") == 0) {
             string regex;
             cin >> regex;

@@ -17,7 +17,7 @@ ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOME
 EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_image_specialize", "mfa_match_batch",
            "mfa_match_batch_regions", "mfa_region_scan", "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_last_region_ms",
            "mfa_device_count", "mfa_last_hip_error", "mfa_strerror", "mfa_version",
-           "mfa_mixed_create", "mfa_mixed_destroy", "mfa_match_mixed", "mfa_mixed_last_ms"]
+           "mfa_mixed_create", "mfa_mixed_destroy", "mfa_match_mixed", "mfa_match_mixed_host", "mfa_mixed_last_ms"]
 
 REGION_WORDS, REGION_MAX, REGION_OVERFLOW, REGION_MIN_LEN = 16, 15, 0x100, 64
 
@@ -71,6 +71,7 @@ def lib():
         L.mfa_mixed_destroy.argtypes = [vp]
         L.mfa_mixed_destroy.restype = None
         L.mfa_match_mixed.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32, vp]
+        L.mfa_match_mixed_host.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32]
         L.mfa_mixed_last_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.mfa_strerror.argtypes = [i32]
         L.mfa_strerror.restype = ctypes.c_char_p

@@ -120,6 +120,39 @@ def test_match_file_drivers(tmp_path):
     assert (tmp_path / "glushkov.dot").read_text().startswith("digraph") and (tmp_path / "thomson.dot").read_text().startswith("digraph")
 
 
+def test_cli_match_mixed(tmp_path):
+    """`./diploma -match-mixed FILE...`: several regexes, each with its own strings, matched by ONE device call
+    (host/automata_host.cpp: match_mixed -> mfa_match_mixed_host); the answers are the goldens'."""
+    import subprocess
+    diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
+    files, want = [], []
+    for name in ("ex1_plain", "ex5_plain", "ex9_plain", "x7_plain"):
+        auto = next(a for a in MANIFEST["automata"] if a["name"] == name)
+        strings = [s for s in oracle_lib.load_set("rnd") if s][:300]
+        bits = oracle_lib.load_bits(name, "rnd")
+        keep = [k for k, s in enumerate(oracle_lib.load_set("rnd")) if s][:300]
+        want += [int(bits[k]) for k in keep]
+        path = tmp_path / (name + ".txt")
+        path.write_bytes(auto["regex"].encode() + b"\n" + b"".join(s + b"\n" for s in strings))
+        files.append(str(path))
+    p = subprocess.run([diploma, "-match-mixed"] + files, capture_output=True, cwd=tmp_path)
+    assert p.returncode == 0, p.stderr
+    assert [int(x) for x in p.stdout.split()] == want
+
+
+def test_require_generated_kernel(tmp_path, monkeypatch):
+    """MFA_REQUIRE_JIT=1: a caller that counts on the specialised kernel gets an error, not silently the other engine; MFA_VERBOSE=1
+    says on stderr which kernel walks."""
+    import subprocess
+    diploma = os.path.join(oracle_lib.ROOT, "re2-modification_amd", "host", "diploma")
+    env = dict(os.environ, MFA_REQUIRE_JIT="1", MFA_WALK="table")
+    p = subprocess.run([diploma, "-match"], input=b"({a*}:1&1)*\naa\nexit\n", capture_output=True, cwd=tmp_path, env=env)
+    assert p.returncode != 0 and b"specialised kernel" in p.stderr
+    env = dict(os.environ, MFA_VERBOSE="1", MFA_WALK="table")
+    p = subprocess.run([diploma, "-match"], input=b"({a*}:1&1)*\naa\nexit\n", capture_output=True, cwd=tmp_path, env=env)
+    assert p.returncode == 0 and b"walk_kernel" in p.stderr and p.stdout.endswith(b"1\n")
+
+
 def test_cli_example_runner(tmp_path):
     """`./diploma -match N` (main.cpp:11-13, matchers/example_runner.cpp:84-151): "len seconds" lines in
     test/example_N/diploma_results.txt, lengths following the reference's schedule (pump size 500, doubling per

@@ -95,8 +95,11 @@ def timing(n_per=125000):
     for engine in os.environ.get("ENGINES", "jit,table").split(","):
         os.environ["MFA_WALK"] = engine
         ims = [capi.Image(image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex))) for ex in layout]
-        for groups in os.environ.get("CUTS", "0.3,0.6,0.8,0.9|0.4,0.7,0.9|0.25,0.5,0.7,0.85,0.95").split("|"):
-            os.environ["MFA_MIXED_CUTS"] = groups
+        for groups in os.environ.get("CUTS", "default").split("|"):
+            if groups == "default":
+                os.environ.pop("MFA_MIXED_CUTS", None)
+            else:
+                os.environ["MFA_MIXED_CUTS"] = groups
             mx = capi.Mixed(ims)
             res = torch.zeros(seg[-1], dtype=torch.uint8, device=dev)
             t = []
