@@ -150,6 +150,9 @@ int  mfa_match_mixed_host(mfa_mixed_t* mx, const uint8_t* bytes, const uint64_t*
 /* device time of the last mfa_match_mixed call on `device`: its region launches, and first region launch to
  * last walk (either pointer may be NULL).  Synchronises on the call's last events. */
 int  mfa_mixed_last_ms(mfa_mixed_t* mx, int device, float* region_ms, float* span_ms);
+/* the same for the call `back` calls ago (0 = the last one; the events of the last 32 calls are kept, so a sequence of calls can be
+ * timed without synchronising between them) */
+int  mfa_mixed_timing(mfa_mixed_t* mx, int device, uint32_t back, float* region_ms, float* span_ms);
 
 /* Same with HOST pointers: copies the batch to the device, matches, copies the
  * results back, synchronises.  Convenience for callers that hold std::strings

@@ -125,7 +125,7 @@ using namespace mfa;
 //   * generated kernels (default while they are the faster walk on small automata): one launch per segment, spread over a few walk
 //     streams by measured cost -- the first call on a device runs the walks one after the other and times them, later calls give
 //     each walk to the stream that can start it first (list scheduling with the groups' region times as release times).
-constexpr uint32_t MIX_MAX_GROUPS = 12, MIX_MAX_STREAMS = 4, MIX_MAX_LAUNCHES = 24;
+constexpr uint32_t MIX_MAX_GROUPS = 12, MIX_MAX_STREAMS = 4, MIX_MAX_LAUNCHES = 24, MIX_TIMINGS = 32;
 
 struct mfa_mixed {
     std::vector<mfa_image*> images;
@@ -140,7 +140,10 @@ struct mfa_mixed {
         hipStream_t ws[MIX_MAX_STREAMS] = {nullptr};           // walk streams
         hipEvent_t ev_g[MIX_MAX_GROUPS] = {nullptr};           // group g's regions are known (timed)
         hipEvent_t ev_w[MIX_MAX_STREAMS] = {nullptr};          // end of a walk stream's work
-        hipEvent_t ev_in = nullptr, ev_r0 = nullptr, ev_end = nullptr;
+        hipEvent_t ev_in = nullptr;
+        // timing of the last MIX_TIMINGS calls (a ring): first region launch, end of the last region launch, end of the call
+        hipEvent_t ev_r0[MIX_TIMINGS] = {nullptr}, ev_r1[MIX_TIMINGS] = {nullptr}, ev_end[MIX_TIMINGS] = {nullptr};
+        uint64_t calls = 0;
         uint64_t* d_regions = nullptr; size_t region_bytes = 0;
         uint32_t* d_spill[MIX_MAX_LAUNCHES] = {nullptr}; size_t spill_bytes[MIX_MAX_LAUNCHES] = {0};
         unsigned long long* d_counters = nullptr;
@@ -199,7 +202,8 @@ void mfa_mixed_destroy(mfa_mixed_t* mx) {
         if (d.d_counters) (void)hipFree(d.d_counters);
         for (hipEvent_t e : d.ev_g) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : d.ev_w) if (e) (void)hipEventDestroy(e);
-        for (hipEvent_t e : {d.ev_in, d.ev_r0, d.ev_end}) if (e) (void)hipEventDestroy(e);
+        if (d.ev_in) (void)hipEventDestroy(d.ev_in);
+        for (uint32_t k = 0; k < MIX_TIMINGS; k++) for (hipEvent_t e : {d.ev_r0[k], d.ev_r1[k], d.ev_end[k]}) if (e) (void)hipEventDestroy(e);
         if (d.rs) (void)hipStreamDestroy(d.rs);
         for (hipStream_t w : d.ws) if (w) (void)hipStreamDestroy(w);
     }
@@ -227,8 +231,7 @@ static int mixed_device(mfa_mixed* mx, int device, mfa_mixed::Dev** out) {
     for (hipEvent_t& e : d.ev_g) HIP_TRY(hipEventCreate(&e));
     for (hipEvent_t& e : d.ev_w) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.ev_in, hipEventDisableTiming));
-    HIP_TRY(hipEventCreate(&d.ev_r0));
-    HIP_TRY(hipEventCreate(&d.ev_end));
+    for (uint32_t k = 0; k < MIX_TIMINGS; k++) { HIP_TRY(hipEventCreate(&d.ev_r0[k])); HIP_TRY(hipEventCreate(&d.ev_r1[k])); HIP_TRY(hipEventCreate(&d.ev_end[k])); }
     d.cost.assign(mx->images.size(), 0.0f);
     auto ins = mx->dev.emplace(device, d);
     *out = &ins.first->second;
@@ -294,7 +297,8 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
     HIP_TRY(hipEventRecord(d->ev_in, cs));
     HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_in, 0));
     for (int k = 0; k < NW; k++) HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_in, 0));
-    HIP_TRY(hipEventRecord(d->ev_r0, d->rs));
+    const uint32_t slot_t = (uint32_t)(d->calls % MIX_TIMINGS);
+    HIP_TRY(hipEventRecord(d->ev_r0[slot_t], d->rs));
     bool used[MIX_MAX_STREAMS] = {false};
     uint32_t slot = 0;                                        // table engine: launches of this call
     for (uint32_t g = 0; g < ng; g++) {
@@ -350,18 +354,20 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
             }
         }
     }
+    HIP_TRY(hipEventRecord(d->ev_r1[slot_t], d->rs));
     // the caller's stream (and the call's end event, on the region stream) wait for every stream that was given work
     for (int k = 0; k < NW; k++)
         if (used[k]) {
             HIP_TRY(hipEventRecord(d->ev_w[k], d->ws[k]));
             HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_w[k], 0));
         }
-    HIP_TRY(hipEventRecord(d->ev_end, d->rs));
-    HIP_TRY(hipStreamWaitEvent(cs, d->ev_end, 0));
+    HIP_TRY(hipEventRecord(d->ev_end[slot_t], d->rs));
+    HIP_TRY(hipStreamWaitEvent(cs, d->ev_end[slot_t], 0));
     d->timed = true;
+    d->calls++;
     d->ng_last = ng;
     if (calibrating) {                                        // once per device: the walks' costs and the groups' region times
-        HIP_TRY(hipEventSynchronize(d->ev_end));
+        HIP_TRY(hipEventSynchronize(d->ev_end[slot_t]));
         for (uint32_t s = 0; s < ns; s++) {
             float ms = 0.0f;
             if (seg_first[s + 1] > seg_first[s] && mfa_last_kernel_ms(mx->images[s], device, &ms) == MFA_OK) d->cost[s] = ms;
@@ -371,7 +377,7 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
             // the calibration pass runs a group's walks before the next group's region launch is reached by nothing: region launches
             // follow each other on their own stream, so the elapsed time between two group events is the later group's region time
             float ms = 0.0f;
-            HIP_TRY(hipEventElapsedTime(&ms, d->ev_r0, d->ev_g[g]));
+            HIP_TRY(hipEventElapsedTime(&ms, d->ev_r0[slot_t], d->ev_g[g]));
             d->ready[g] = ms; prev = ms;
         }
         (void)prev;
@@ -415,18 +421,22 @@ int mfa_match_mixed_host(mfa_mixed_t* mx, const uint8_t* bytes, const uint64_t* 
     return rc;
 }
 
-// Device time of the last mfa_match_mixed on `device`: from its first region launch to the end of its last region launch, and to
-// the end of its last walk (either pointer may be NULL).  Synchronises on the call's end.
-int mfa_mixed_last_ms(mfa_mixed_t* mx, int device, float* region_ms, float* span_ms) {
+// Device time of a recent mfa_match_mixed on `device`: from its first region launch to the end of its last region launch, and to the
+// end of its last walk (either pointer may be NULL).  back = 0: the last call, 1: the one before, ... (the library keeps the events
+// of its last 32 calls, so a caller can time a sequence of calls without synchronising between them).  Synchronises on that call's end.
+int mfa_mixed_timing(mfa_mixed_t* mx, int device, uint32_t back, float* region_ms, float* span_ms) {
     if (!mx) return MFA_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(mx->mu);
     auto it = mx->dev.find(device);
-    if (it == mx->dev.end() || !it->second.timed) return MFA_ERR_INVALID_ARG;
+    if (it == mx->dev.end() || !it->second.timed || back >= MIX_TIMINGS || back >= it->second.calls) return MFA_ERR_INVALID_ARG;
     mfa_mixed::Dev& d = it->second;
-    HIP_TRY(hipEventSynchronize(d.ev_end));
-    if (region_ms) HIP_TRY(hipEventElapsedTime(region_ms, d.ev_r0, d.ev_g[d.ng_last ? d.ng_last - 1 : 0]));
-    if (span_ms) HIP_TRY(hipEventElapsedTime(span_ms, d.ev_r0, d.ev_end));
+    const uint32_t k = (uint32_t)((d.calls - 1 - back) % MIX_TIMINGS);
+    HIP_TRY(hipEventSynchronize(d.ev_end[k]));
+    if (region_ms) HIP_TRY(hipEventElapsedTime(region_ms, d.ev_r0[k], d.ev_r1[k]));
+    if (span_ms) HIP_TRY(hipEventElapsedTime(span_ms, d.ev_r0[k], d.ev_end[k]));
     return MFA_OK;
 }
+
+int mfa_mixed_last_ms(mfa_mixed_t* mx, int device, float* region_ms, float* span_ms) { return mfa_mixed_timing(mx, device, 0u, region_ms, span_ms); }
 
 }  // extern "C"

@@ -17,7 +17,7 @@ ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOME
 EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_image_specialize", "mfa_match_batch",
            "mfa_match_batch_regions", "mfa_region_scan", "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_last_region_ms",
            "mfa_device_count", "mfa_last_hip_error", "mfa_strerror", "mfa_version",
-           "mfa_mixed_create", "mfa_mixed_destroy", "mfa_match_mixed", "mfa_match_mixed_host", "mfa_mixed_last_ms"]
+           "mfa_mixed_create", "mfa_mixed_destroy", "mfa_match_mixed", "mfa_match_mixed_host", "mfa_mixed_last_ms", "mfa_mixed_timing"]
 
 REGION_WORDS, REGION_MAX, REGION_OVERFLOW, REGION_MIN_LEN = 16, 15, 0x100, 64
 
@@ -73,6 +73,7 @@ def lib():
         L.mfa_match_mixed.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32, vp]
         L.mfa_match_mixed_host.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32]
         L.mfa_mixed_last_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
+        L.mfa_mixed_timing.argtypes = [vp, i32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.mfa_strerror.argtypes = [i32]
         L.mfa_strerror.restype = ctypes.c_char_p
         L.mfa_version.restype = ctypes.c_char_p
@@ -194,10 +195,10 @@ class Mixed:
                                      ctypes.c_void_p(s.cuda_stream)), "mfa_match_mixed")
         return d_results[:n]
 
-    def last_ms(self, device=0):
-        """(region launches, first region launch to last walk) of the last call, in ms"""
+    def last_ms(self, device=0, back=0):
+        """(region launches, first region launch to last walk) of the call `back` calls ago (0 = the last one), in ms"""
         r, sp = ctypes.c_float(), ctypes.c_float()
-        _check(lib().mfa_mixed_last_ms(self._h, device, ctypes.byref(r), ctypes.byref(sp)), "mfa_mixed_last_ms")
+        _check(lib().mfa_mixed_timing(self._h, device, back, ctypes.byref(r), ctypes.byref(sp)), "mfa_mixed_timing")
         return r.value, sp.value
 
     def close(self):
