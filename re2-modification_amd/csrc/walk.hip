@@ -45,7 +45,7 @@ struct TicketFeeder {
 
 // LDS of a workgroup: [tables] then per wave [lv][ld][sb][sa][rt_cache]
 // TG: the tables stay in global memory (automata whose tables do not fit LDS beside the lists)
-template <int K, bool REV, bool STATS, bool TG>
+template <int K, bool REV, bool STATS, bool TG, int NKEYS>
 __global__ void __launch_bounds__(256, WALK_MIN_WAVES)
 walk_kernel(WalkArgs a) {
     extern __shared__ uint32_t smem[];
@@ -105,6 +105,8 @@ static size_t wave_words(uint32_t C, bool images_global) {
 
 #if WALK_STATS
 int launch_walk_stats(const WalkLaunch& L, void* stream) {
+#elif defined(WALK_LONG_LISTS)
+int WALK_CAT(launch_walk_long_k, WALK_K)(const WalkLaunch& L, void* stream) {
 #else
 int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
 #endif
@@ -115,8 +117,8 @@ int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
     hipError_t e = hipSuccess;
 #define WALK_GO(REVV, TGV)                                                                                                                   \
     do {                                                                                                                                     \
-        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, REVV, WALK_STATS != 0, TGV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, REVV, WALK_STATS != 0, TGV>), dim3(L.grid), dim3(256), lds, s, a);          \
+        e = hipFuncSetAttribute((const void*)walk_kernel<WALK_K, REVV, WALK_STATS != 0, TGV, WALK_KEYS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e == hipSuccess) hipLaunchKernelGGL((walk_kernel<WALK_K, REVV, WALK_STATS != 0, TGV, WALK_KEYS>), dim3(L.grid), dim3(256), lds, s, a);          \
     } while (0)
     if (L.tables_global) { if (L.reversed) WALK_GO(true, true); else WALK_GO(false, true); }
     else { if (L.reversed) WALK_GO(true, false); else WALK_GO(false, false); }
@@ -126,7 +128,7 @@ int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
     return MFA_OK;
 }
 
-#if !WALK_STATS
+#if !WALK_STATS && !defined(WALK_LONG_LISTS)
 size_t WALK_CAT(walk_wave_words_k, WALK_K)(uint32_t C, bool images_global) { return wave_words(C, images_global); }
 #endif
 

@@ -95,6 +95,7 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
         if (rc == MFA_OK) { (void)hipStreamSynchronize((hipStream_t)stream); walk_print_stats(d_counter, "walk"); }
         return rc;
     }
+    if (p.K == 1 && p.max_live > 16u && env_int("MFA_WALK_LONG", 1) != 0) return launch_walk_long_k1(L, stream);
     switch (p.K) {
         case 1: return launch_walk_k1(L, stream); case 2: return launch_walk_k2(L, stream); case 3: return launch_walk_k3(L, stream);
         case 4: return launch_walk_k4(L, stream); case 5: return launch_walk_k5(L, stream); case 6: return launch_walk_k6(L, stream);

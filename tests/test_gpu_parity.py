@@ -610,6 +610,52 @@ def test_mixed_batch_in_one_call(monkeypatch):
         assert np.array_equal(got, want), layout[k]
 
 
+def test_mixed_batch_corner_cases(tmp_path, monkeypatch):
+    """mfa_match_mixed beyond the headline shape: reversed automata in one launch (a launch scans in one direction), an automaton
+    with 7 cells among automata with 1-2 (every table of the launch is then read with 3-word edges), an empty segment, and a mix
+    of scan directions, which the table engine refuses and the per-segment engine matches."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(77)
+
+    def batch_of(lists):
+        strings = [s for l in lists for s in l]
+        seg = [0]
+        for l in lists:
+            seg.append(seg[-1] + len(l))
+        data, off = oracle_lib.pack(strings if strings else [b""])
+        d_bytes = torch.zeros(len(data) + 64, dtype=torch.uint8, device=dev)
+        d_bytes[:len(data)] = torch.from_numpy(data.copy())
+        return d_bytes, torch.from_numpy(off.astype(np.int64)).to(dev), seg, strings
+
+    def texts(n):
+        out = []
+        for _ in range(n):
+            u = bytes(rng.choice(list(b"ab"), size=int(rng.integers(1, 6))).tolist())
+            out.append(u * int(rng.integers(1, 500)) + bytes(rng.choice(list(b"abc"), size=int(rng.integers(0, 3))).tolist()))
+        return out
+
+    cases = {
+        "reversed": [image.blob_from_dump(oracle_lib.load_dump(n)) for n in ("ex3_reverse", "ex6_reverse", "ex8_reverse", "ex2_reverse")],
+        "wide": [image.blob_from_dump(oracle_lib.load_dump("ex1_plain")), _front_end_blob(MANY_CELLS_TIES[1], tmp_path), image.blob_from_dump(oracle_lib.load_dump("ex5_plain"))],
+        "mixed directions": [image.blob_from_dump(oracle_lib.load_dump("ex1_plain")), image.blob_from_dump(oracle_lib.load_dump("ex3_reverse"))],
+    }
+    for name, blobs in cases.items():
+        lists = [texts(int(rng.integers(150, 400))) for _ in blobs]
+        if name == "reversed":
+            lists[1] = []                                           # an empty segment
+        d_bytes, d_off, seg, strings = batch_of(lists)
+        want = np.concatenate([oracle_lib.OracleImage(b).match(l) if l else np.zeros(0, dtype=np.uint8) for b, l in zip(blobs, lists)])
+        for engine in ("table", "specialised"):
+            use_engine(monkeypatch, engine)
+            images = [capi.Image(b) for b in blobs]
+            mx = capi.Mixed(images)
+            got = mx.match_tensors(d_bytes, d_off, seg)
+            torch.cuda.synchronize()
+            assert np.array_equal(got.cpu().numpy(), want), (name, engine)
+            mx.close()
+
+
 def test_more_than_128_nodes(tmp_path, monkeypatch):
     """beyond the generated kernels' 128 nodes: a memory automaton with several hundred nodes (a long literal chain around a
     back-reference) walked by the table-driven kernel, against the CPU restatement"""
