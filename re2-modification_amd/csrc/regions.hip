@@ -98,10 +98,17 @@ struct RegionState {
     int32_t  last_dirty[9];      // per period: the last dirty block seen (scalar registers after unrolling)
     int32_t  cand_x[9], cand_y[9];   // per period: the candidate recorded last
     uint32_t ncand;              // candidates recorded so far (wave-uniform)
+    uint32_t shortest;           // with 64 candidates held: the shortest one, length in blocks << 6 | lane (~0u: not known; wave-uniform)
     // candidate e lives in lane e
     uint32_t cq;
     int32_t  cx, cy;
 };
+
+__device__ __forceinline__ uint32_t shortest_candidate(const RegionState& st, uint32_t lane) {
+    uint32_t key = ((uint32_t)(st.cy - st.cx) << 6) | lane;                // length in blocks (< 2^20) | lane
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(key, o); key = t < key ? t : key; }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+}
 
 // A candidate of period Q that a candidate of a proper divisor of Q covers (to within a block at either end) is not recorded:
 // the divisor's region says more.  Divisors are handled before Q in every row, so their candidates for the same stretch exist.
@@ -114,14 +121,17 @@ __device__ __forceinline__ void emit(RegionState& st, uint32_t lane, int32_t x, 
     if (st.ncand < 64u) {
         if (lane == st.ncand) { st.cq = Q; st.cx = x; st.cy = y; }
         st.ncand++;
+        st.shortest = ~0u;
         return;
     }
     // More candidates than lanes (text made of hundreds of medium runs): the new one takes the place of the shortest if it is longer,
     // so that a long periodic stretch BEHIND such text is still in the table (the walk jumps over what the table holds and executes
-    // everything else step by step).  The table then carries the overflow flag (ncand stays at 64).
-    uint32_t key = ((uint32_t)(st.cy - st.cx) << 6) | lane;                // length in blocks (< 2^20) | lane
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(key, o); key = t < key ? t : key; }
-    if ((uint32_t)(y - x) > (key >> 6) && lane == (key & 63u)) { st.cq = Q; st.cx = x; st.cy = y; }
+    // everything else step by step).  The table then carries the overflow flag (ncand stays at 64).  The shortest candidate held
+    // (length in blocks << 6 | its lane) is kept as a scalar: most candidates of such text are no longer than it and cost one compare.
+    if (st.shortest == ~0u) st.shortest = shortest_candidate(st, lane);
+    if ((uint32_t)(y - x) <= (st.shortest >> 6)) return;
+    if (lane == (st.shortest & 63u)) { st.cq = Q; st.cx = x; st.cy = y; }
+    st.shortest = shortest_candidate(st, lane);
 }
 
 // book-keeping of one row for one period: dirty = ballot of dirty blocks, base = block number of lane 0
@@ -140,13 +150,14 @@ __device__ __forceinline__ bool book(RegionState& st, uint32_t lane, unsigned lo
 #pragma unroll
     for (int k = 1; k < kCleanMin; k++) zz &= z >> k;
     const unsigned long long inside = first < top ? ((~0ull >> (63 - top)) & (~0ull << first)) : 0ull;
-    if (zz & inside) {
-        int32_t prev = first;
-        for (unsigned long long m = dirty & (dirty - 1ull); m; m &= m - 1ull) {
-            const int32_t nxt = (int32_t)__builtin_ctzll(m);
-            if (nxt - prev - 1 >= kCleanMin) { emit<Q>(st, lane, base + prev, base + nxt); emitted = true; }
-            prev = nxt;
-        }
+    // bit s of zz: blocks s .. s + kCleanMin - 1 are clean.  The lowest such bit inside (first, top) starts a stretch (the block before it is dirty),
+    // the first dirty block from there on ends it: one trip per stretch that makes a candidate, not one per dirty block
+    for (unsigned long long w = zz & inside; w;) {
+        const int32_t s = (int32_t)__builtin_ctzll(w);
+        const int32_t e = s + (int32_t)__builtin_ctzll(dirty >> s);
+        emit<Q>(st, lane, base + s - 1, base + e);
+        emitted = true;
+        w &= ~0ull << e;
     }
     last = base + top;
     return emitted;
@@ -171,12 +182,29 @@ __device__ __forceinline__ bool row_same_as(RegionState& st, RowBook& rb) {
     }
 }
 
+// Where every block that is clean for Q is clean for a proper divisor D as well (this row's, and the stretch reaching into it: D's last dirty
+// block is no later than Q's), whatever Q's book-keeping recorded would lie inside D's candidate: Q only notes its last dirty block.  (Text of
+// runs of one byte broken by single other bytes: the blocks dirty for period 1 are dirty for every period -- without this all eight periods
+// went through their stretches, 8 x the scalar work of such rows, and filled the candidate lanes with covered copies.)
+template <int Q, int D>
+__device__ __forceinline__ bool row_inside(RegionState& st, RowBook& rb, int32_t base) {
+    if constexpr (D >= Q || Q % D != 0) return false;
+    else {
+        if ((rb.dirty[D] & ~rb.dirty[Q]) != 0ull || rb.before[Q] < rb.before[D] || rb.dirty[Q] == 0ull) return false;
+        st.last_dirty[Q] = base + 63 - (int32_t)__builtin_clzll(rb.dirty[Q]);
+        rb.emitted[Q] = false;
+        return true;
+    }
+}
+
 template <int Q>
 __device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, uint32_t mask, uint32_t settled, int32_t base, RowBook& rb) {
     if (settled & qbit(Q)) st.last_dirty[Q] = base - 1;        // every block of the rows skipped before this one was dirty
     rb.dirty[Q] = __ballot((mask & qbit(Q)) != 0u);
     rb.before[Q] = st.last_dirty[Q];
+    if (row_inside<Q, 1>(st, rb, base)) return;                // the cheapest test first: such rows are the ones that come in thousands per string
     if (row_same_as<Q, 4>(st, rb) || row_same_as<Q, 3>(st, rb) || row_same_as<Q, 2>(st, rb) || row_same_as<Q, 1>(st, rb)) return;
+    if (row_inside<Q, 2>(st, rb, base) || row_inside<Q, 3>(st, rb, base) || row_inside<Q, 4>(st, rb, base)) return;
     rb.emitted[Q] = book<Q>(st, lane, rb.dirty[Q], base);
 }
 
@@ -212,7 +240,7 @@ struct Scan {
 __device__ __forceinline__ void scan_reset(Scan& sc) {
 #pragma unroll
     for (int q = 0; q < 9; q++) { sc.st.last_dirty[q] = -1; sc.st.cand_x[q] = 0x7fffffff; sc.st.cand_y[q] = -1; }
-    sc.st.ncand = 0; sc.st.cq = 0; sc.st.cx = 0; sc.st.cy = 0;
+    sc.st.ncand = 0; sc.st.shortest = ~0u; sc.st.cq = 0; sc.st.cx = 0; sc.st.cy = 0;
     sc.settled = ~0u; sc.vp = 0u;
 }
 
