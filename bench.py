@@ -673,6 +673,7 @@ def main():
                          "kernel": "region_scan_kernel (%d launches over groups of strings, on one stream) + %s; duration = first region launch to end of the last walk" % (
                              n_groups, engine),
                          "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s,
+                         "kernel_ms_by_step": [round(x, 3) for x in span_ms[::-1]],
                          # the kernel that reads the bytes: its own launches, back to back on their stream, timed with HIP events
                          "region_scan_kernel": {"launches_per_step": n_groups, "ms_per_step": reg_total_ms,
                                                 "ms_per_launch": reg_total_ms / n_groups,

@@ -104,10 +104,21 @@ struct RegionState {
     int32_t  cx, cy;
 };
 
+// wave-wide minimum by DPP (six V_MIN_U32 with a row shift or a row broadcast as operand, the result read from lane 63): emit() is inlined
+// for every period and row in flight, and the usual exchange through the LDS crossbar was 35 instructions at each of its 64 copies
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+#define MFA_DPP_MIN(ctrl, rows) { const uint32_t t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, ctrl, rows, 0xf, false); v = t < v ? t : v; }
+    MFA_DPP_MIN(0x111, 0xf)      // row_shr:1   lane i: min over i-1 .. i   (lanes without a source keep their own value)
+    MFA_DPP_MIN(0x112, 0xf)      // row_shr:2             i-3 .. i
+    MFA_DPP_MIN(0x114, 0xf)      // row_shr:4             i-7 .. i
+    MFA_DPP_MIN(0x118, 0xf)      // row_shr:8             i-15 .. i: lane 15 of every row of 16 holds the row's minimum
+    MFA_DPP_MIN(0x142, 0xa)      // row_bcast:15 into rows 1 and 3
+    MFA_DPP_MIN(0x143, 0xc)      // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's
+#undef MFA_DPP_MIN
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ uint32_t shortest_candidate(const RegionState& st, uint32_t lane) {
-    uint32_t key = ((uint32_t)(st.cy - st.cx) << 6) | lane;                // length in blocks (< 2^20) | lane
-    for (int o = 32; o > 0; o >>= 1) { const uint32_t t = __shfl_xor(key, o); key = t < key ? t : key; }
-    return (uint32_t)__builtin_amdgcn_readfirstlane((int)key);
+    return wave_min_u32(((uint32_t)(st.cy - st.cx) << 6) | lane);          // length in blocks (< 2^20) | lane
 }
 
 // A candidate of period Q that a candidate of a proper divisor of Q covers (to within a block at either end) is not recorded:
@@ -131,7 +142,7 @@ __device__ __forceinline__ void emit(RegionState& st, uint32_t lane, int32_t x, 
     if (st.shortest == ~0u) st.shortest = shortest_candidate(st, lane);
     if ((uint32_t)(y - x) <= (st.shortest >> 6)) return;
     if (lane == (st.shortest & 63u)) { st.cq = Q; st.cx = x; st.cy = y; }
-    st.shortest = shortest_candidate(st, lane);
+    st.shortest = ~0u;
 }
 
 // book-keeping of one row for one period: dirty = ballot of dirty blocks, base = block number of lane 0
