@@ -305,6 +305,19 @@ def secondary_config3(device, capi, n_strings=1 << 20, length=65536):
     res = torch.empty(n_strings, dtype=torch.uint8, device=device)
     t, tr = _timed(img, flat, off, res, device, reps=2)
     nbytes = n_strings * length
+    # the same batch through mfa_match_mixed (one image): groups of strings, the walks of a group beside the region pass of the next
+    mx = capi.Mixed([img])
+    res_m = torch.empty(n_strings, dtype=torch.uint8, device=device)
+    spans = []
+    for _ in range(3):
+        mx.match_tensors(flat, off, [0, n_strings], res_m); torch.cuda.synchronize()
+        spans.append(mx.last_ms(device.index or 0))
+    span, span_region = float(np.mean([x[1] for x in spans[1:]])), float(np.mean([x[0] for x in spans[1:]]))
+    mixed_kernel = KERNEL_NAMES.get(img.info()["last_kernel"], "?")
+    same = bool(torch.equal(res, res_m))
+    mx.close()
+    img.match_tensors(flat, off, res)          # (the per-image engine again: the kernel name reported below)
+    del res_m
     # strings with more periodic stretches than a table row holds (text made of hundreds of medium runs, here the a/b noise strings):
     # the pass reads them to their end all the same and keeps the longest stretches
     tab = capi.region_scan(flat, off)
@@ -320,6 +333,8 @@ def secondary_config3(device, capi, n_strings=1 << 20, length=65536):
     return {"workload": "configs[2]: ({a*}:1&1)*, %d strings of exactly %d bytes (%.1f GB), 4-way attack mix" % (n_strings, length, nbytes / 1e9),
             "kernel": "region_scan_kernel + " + KERNEL_NAMES.get(img.info()["last_kernel"], "?"), "region_ms": tr, "walk_ms": t,
             "GB/s_on_sum_of_lengths": nbytes / ((t + tr) * 1e-3) / 1e9,
+            "mixed_call": {"kernel": "mfa_match_mixed: region_scan_kernel + " + mixed_kernel, "span_ms": span, "region_ms": span_region, "GB/s_on_sum_of_lengths": nbytes / (span * 1e-3) / 1e9,
+                           "frac_of_hbm_peak_on_touched_bytes": nbytes / (span * 1e-3) / 1e9 / HBM_PEAK_GBS, "results_equal": same},
             # the walk stops at the first empty state set (mfa.cpp:224-225), but the region pass has read every byte by then
             "touched_bytes": nbytes,
             "touched_by": "region_scan_kernel reads every byte of every string (%d strings, %.1f %%, have more stretches than a table row holds: "

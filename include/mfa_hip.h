@@ -112,7 +112,7 @@ int  mfa_match_batch(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* d
  * Table layout: MFA_REGION_WORDS uint64 per string; word 0 = count | flags, then `count` entries
  *   lo | hi << 24 | q << 48     (offsets relative to the start of the string, memory order)
  * Every entry is true (s[j] == s[j+q] for lo <= j < hi - q) and entries with q = 1 are maximal runs.
- * MFA_REGION_OVERFLOW in word 0: the string has more regions than fit and the table holds the longest
+ * MFA_REGION_OVERFLOW in word 0: the string has more regions than fit and the table holds the first three and the longest of the others
  * (or the string is too long to be matched): the walk then executes the other stretches step by step. */
 #define MFA_REGION_WORDS    16u
 #define MFA_REGION_MAX      15u

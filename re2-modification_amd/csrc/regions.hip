@@ -14,7 +14,7 @@
 // Table of a string (MFA_REGION_WORDS u64 words): word 0 = header, then up to MFA_REGION_MAX entries
 //   entry  = lo | hi << 24 | q << 48
 //   header = count | MFA_REGION_OVERFLOW  (overflow: the string has more regions than fit and the table
-//            holds the longest ones, or the string is too long to be matched at all)
+//            holds the first three and the longest of the others, or the string is too long to be matched at all)
 // Guarantees the walk kernels rely on:
 //   (1) every entry is true: s[j] == s[j+q] for lo <= j < hi - q;
 //   (2) entries with q = 1 are maximal at both ends (cell reads of one-byte-repeated values compare
@@ -117,8 +117,12 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
 #undef MFA_DPP_MIN
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// The candidates recorded first (lanes 0 .. kEarly - 1) are never given up: a walk that fails early -- the usual fate of an attack string
+// under an automaton it does not fit -- only ever needs the first stretches, and stepping through them byte by byte is what a table
+// without them costs.
+static constexpr uint32_t kEarly = 3;
 __device__ __forceinline__ uint32_t shortest_candidate(const RegionState& st, uint32_t lane) {
-    return wave_min_u32(((uint32_t)(st.cy - st.cx) << 6) | lane);          // length in blocks (< 2^20) | lane
+    return wave_min_u32(lane < kEarly ? 0xffffffc0u | lane : ((uint32_t)(st.cy - st.cx) << 6) | lane);          // length in blocks (< 2^20) | lane
 }
 
 // A candidate of period Q that a candidate of a proper divisor of Q covers (to within a block at either end) is not recorded:
@@ -410,14 +414,24 @@ __device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo
     }
     unsigned long long kb = __ballot(keep);
     const uint32_t total = (uint32_t)__builtin_popcountll(kb);
-    if (total > MFA_REGION_MAX) {                          // more than fit: the longest stay
+    if (total > MFA_REGION_MAX) {                          // more than fit: the first kEarly stay (see shortest_candidate), and the longest of the others
+        const uint32_t pkey = (lo << 4) | q;
+        uint32_t before = 0;
+        for (unsigned long long m = kb; m; m &= m - 1ull) {
+            const int f = __builtin_ctzll(m);
+            const uint32_t kf = (uint32_t)__builtin_amdgcn_readlane((int)pkey, f);
+            if (kf < pkey || (kf == pkey && (uint32_t)f < lane)) before++;
+        }
+        const bool early = keep && before < kEarly;
+        const unsigned long long eb = __ballot(early);
         const uint32_t mine = hi - lo;
         uint32_t longer = 0;
-        for (uint32_t f = 0; f < ncand; f++) {
-            const uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)f);
-            if (((kb >> f) & 1ull) && (lf > mine || (lf == mine && f < lane))) longer++;
+        for (unsigned long long m = kb & ~eb; m; m &= m - 1ull) {
+            const int f = __builtin_ctzll(m);
+            const uint32_t lf = (uint32_t)__builtin_amdgcn_readlane((int)mine, f);
+            if (lf > mine || (lf == mine && (uint32_t)f < lane)) longer++;
         }
-        keep = keep && longer < MFA_REGION_MAX;
+        keep = keep && (early || longer < MFA_REGION_MAX - (uint32_t)__builtin_popcountll(eb));
         kb = __ballot(keep);
     }
     // entries go out in the order of their starts (the walk kernels copy the first few to LDS: the ones they meet first)
@@ -445,14 +459,20 @@ constexpr int kRegionDepth = 2;      // 3 and 4 are more robust alone at low occ
 // start-up latencies as well as software pipelining does.
 template <int MODE, int DEPTH, bool SAFE>
 __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
-                                                             uint64_t* __restrict__ table) {
+                                                             uint64_t* __restrict__ table, uint32_t rotate) {
     const uint32_t lane = threadIdx.x & 63u;
     // the wave's number as a scalar: string offsets and everything derived from them then live in scalar registers
     const uint32_t wpb = blockDim.x >> 6;                                // waves per workgroup (4; 1 or 2 as a development variant)
     const uint64_t wave = (uint64_t)blockIdx.x * wpb + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = (uint64_t)gridDim.x * wpb;
     const uint64_t total16 = (offsets[n] + 15u) & ~(uint64_t)15;        // the batch is readable below this offset
     const uint64_t ymax = total16 - 8u;
-    for (uint64_t sid = wave; sid < n; sid += n_waves) {
+    for (uint64_t turn = wave; turn < n; turn += n_waves) {
+        // Which string a wave takes is rotated within blocks of 64 by an amount that changes from block to block.  Workgroups go to
+        // the eight XCDs in turn, so in a batch whose strings repeat a pattern of costs with a small period (BASELINE configs[2]: every
+        // fourth string is text of many short runs, 4 x the scalar work) the expensive strings of EVERY round fell to the same XCDs:
+        // 6.8 ms against 3.8 ms for the same batch with two-wave and four-wave workgroups.
+        uint64_t sid = turn;
+        if (rotate && (turn | 63ull) < n) sid = (turn & ~63ull) | ((turn + 17ull * (turn >> 6)) & 63ull);
         const uint64_t b = offsets[sid], e = offsets[sid + 1];
         uint64_t* const tab = table + sid * MFA_REGION_WORDS;
         if (e - b > kMaxLen) { if (lane == 0) tab[0] = MFA_REGION_OVERFLOW; continue; }
@@ -511,13 +531,15 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     const int depth = ed ? atoi(ed) : kRegionDepth;
     // development: MFA_REGION_SAFE_WAITS=1 waits for every outstanding load before a row is looked at, instead of counting on the
     // order of the requests (tests/test_regions_gpu.py compares the tables of the two modes)
+    const char* er = getenv("MFA_REGION_ROTATE");                 // development: 0 = wave w takes string w
+    const uint32_t rotate = er && er[0] == '0' ? 0u : 1u;
     const char* es = getenv("MFA_REGION_SAFE_WAITS");
     const bool safe = es && es[0] == '1';
-    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (safe) hipLaunchKernelGGL((region_scan_kernel<0, 2, true>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
-    else if (depth == 3) hipLaunchKernelGGL((region_scan_kernel<0, 3, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table);
+    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
+    else if (safe) hipLaunchKernelGGL((region_scan_kernel<0, 2, true>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
+    else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
+    else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
+    else if (depth == 3) hipLaunchKernelGGL((region_scan_kernel<0, 3, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else return MFA_ERR_UNSUPPORTED;
     HIP_TRY(hipGetLastError());
     return MFA_OK;

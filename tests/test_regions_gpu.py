@@ -183,6 +183,31 @@ def test_region_tables_every_rotation_depth(depth, monkeypatch):
     check_tables(strings, got)
 
 
+def test_overflowing_table_keeps_the_first_regions():
+    """A string with hundreds of medium runs: the table keeps the longest stretches AND the first ones -- a walk that dies at the
+    first foreign byte (BASELINE configs[2]'s noise strings under example 1) must not step through the first run byte by byte."""
+    rng = np.random.default_rng(65)
+    strings = [b"".join(bytes([97 + (k % 2)]) * int(rng.integers(100, 131)) for k in range(300)),
+               bytes(np.where(rng.random(65536) < 0.01, 98, 97).astype(np.uint8).tobytes())]
+    tabs = scan(strings)
+    check_tables(strings, tabs)
+    for s, row in zip(strings, tabs):
+        entries, overflow = decode(row)
+        assert overflow and len(entries) == 15
+        # the first run of at least 128 equal bytes is a candidate whatever its alignment (six whole clean blocks): it, or an earlier one, is there
+        k, first = 0, None
+        while k < len(s) and first is None:
+            j = k
+            while j < len(s) and s[j] == s[k]:
+                j += 1
+            if j - k >= 128:
+                first = (k, j)
+            k = j
+        assert first is not None
+        assert any(lo <= first[0] and q == 1 for lo, hi, q in entries), (first, sorted(entries)[:4])
+        assert any(lo == first[0] and hi == first[1] and q == 1 for lo, hi, q in entries) or min(lo for lo, hi, q in entries) < first[0]
+
+
 def test_region_table_overflow_keeps_true_regions():
     """more long regions than a table holds: flagged, and what is kept is still true"""
     s = b"".join(bytes([97 + (k % 3)]) * 150 for k in range(60))

@@ -20,3 +20,5 @@ for s in d.get("secondary", []):
                                                  {k: par[k] for k in ("strings", "max_len", "mismatches") if k in par}))
     if "frac_of_hbm_peak_on_touched_bytes" in s:
         print("    frac on touched bytes:", s["frac_of_hbm_peak_on_touched_bytes"])
+    if "mixed_call" in s:
+        print("    mixed call:", s["mixed_call"])
