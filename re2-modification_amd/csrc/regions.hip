@@ -213,16 +213,18 @@ __device__ __forceinline__ bool row_inside(RegionState& st, RowBook& rb, int32_t
 }
 
 template <int Q>
-__device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, uint32_t mask, uint32_t settled, int32_t base, RowBook& rb) {
+__device__ __forceinline__ void row_prep(RegionState& st, uint32_t mask, uint32_t settled, int32_t base, RowBook& rb) {
     if (settled & qbit(Q)) st.last_dirty[Q] = base - 1;        // every block of the rows skipped before this one was dirty
     rb.dirty[Q] = __ballot((mask & qbit(Q)) != 0u);
     rb.before[Q] = st.last_dirty[Q];
-    if (row_inside<Q, 1>(st, rb, base)) return;                // the cheapest test first: such rows are the ones that come in thousands per string
+}
+template <int Q>
+__device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, int32_t base, RowBook& rb) {
+    if (row_inside<Q, 1>(st, rb, base)) return;
     if (row_same_as<Q, 4>(st, rb) || row_same_as<Q, 3>(st, rb) || row_same_as<Q, 2>(st, rb) || row_same_as<Q, 1>(st, rb)) return;
     if (row_inside<Q, 2>(st, rb, base) || row_inside<Q, 3>(st, rb, base) || row_inside<Q, 4>(st, rb, base)) return;
     rb.emitted[Q] = book<Q>(st, lane, rb.dirty[Q], base);
 }
-
 // ---- one string ---------------------------------------------------------------------------------------------
 struct Geo {                 // where a string lies: blocks are the 16-byte aligned blocks of the batch it touches
     uint64_t a0;             // offset of block 0 in the batch
@@ -335,26 +337,41 @@ __device__ __forceinline__ void scan_row(Scan& sc, uint32_t lane, const Geo& g, 
     if (__all(mask == sc.settled)) return;
     const uint32_t was = sc.settled != ~0u ? sc.settled : 0u;
     RowBook rb;
-    row_period<1>(st, lane, mask, was, base, rb);
-    row_period<2>(st, lane, mask, was, base, rb);
-    row_period<3>(st, lane, mask, was, base, rb);
-    row_period<4>(st, lane, mask, was, base, rb);
-    row_period<5>(st, lane, mask, was, base, rb);
-    row_period<6>(st, lane, mask, was, base, rb);
-    row_period<7>(st, lane, mask, was, base, rb);
-    row_period<8>(st, lane, mask, was, base, rb);
+    row_prep<1>(st, mask, was, base, rb);
+    rb.emitted[1] = book<1>(st, lane, rb.dirty[1], base);
+    // Rows of runs of one byte broken by other bytes (thousands per string in text of that kind, and the rows where a run of the attack
+    // corpus ends): every block that is dirty for period 1 is dirty for all periods, and no period's clean stretch reaches further back
+    // than period 1's -- row_inside<Q, 1> for the seven other periods, decided before any of them does its book-keeping: they only
+    // note their last dirty block.  (The ballots are taken again on the other path: keeping all eight alive spilled scalar registers.)
+    bool inside = rb.dirty[1] != 0ull;
+    int32_t nl[9];
+#define MFA_TRY_INSIDE(Q) { const int32_t bq = (was & qbit(Q)) ? base - 1 : st.last_dirty[Q]; const unsigned long long dq = __ballot((mask & qbit(Q)) != 0u); \
+                            inside = inside && (rb.dirty[1] & ~dq) == 0ull && bq >= rb.before[1]; nl[Q] = base + 63 - (int32_t)__builtin_clzll(dq | 1ull); }
+    MFA_TRY_INSIDE(2) MFA_TRY_INSIDE(3) MFA_TRY_INSIDE(4) MFA_TRY_INSIDE(5) MFA_TRY_INSIDE(6) MFA_TRY_INSIDE(7) MFA_TRY_INSIDE(8)
+#undef MFA_TRY_INSIDE
+    if (inside) {
+#pragma unroll
+        for (int q = 2; q <= 8; q++) st.last_dirty[q] = nl[q];
+    } else {
+        row_prep<2>(st, mask, was, base, rb); row_period<2>(st, lane, base, rb);
+        row_prep<3>(st, mask, was, base, rb); row_period<3>(st, lane, base, rb);
+        row_prep<4>(st, mask, was, base, rb); row_period<4>(st, lane, base, rb);
+        row_prep<5>(st, mask, was, base, rb); row_period<5>(st, lane, base, rb);
+        row_prep<6>(st, mask, was, base, rb); row_period<6>(st, lane, base, rb);
+        row_prep<7>(st, mask, was, base, rb); row_period<7>(st, lane, base, rb);
+        row_prep<8>(st, mask, was, base, rb); row_period<8>(st, lane, base, rb);
+    }
     // What the next rows are compared with is the mask of this row's LAST block: rows that are uniformly like it continue its
     // stretch (a block clean for a period looks 8 bytes beyond itself, so the first bytes of the next row are covered), and a row
     // that is uniformly dirty for a period follows a block that was.  Waiting for a whole uniform row instead cost one more trip
     // through this book-keeping after every string start and every region boundary.
     const int32_t b63 = base + 63;
     sc.settled = (b63 < g.endblk) ? (uint32_t)__builtin_amdgcn_readlane((int)mask, 63) : ~0u;
-    sc.vp = 0u;
-    if (sc.settled != ~0u) {
-#pragma unroll
-        for (int q = 8; q >= 1; q--)
-            if (!(sc.settled & qbit(q))) sc.vp = (uint32_t)q;
-    }
+    // the smallest clean period of that mask (odd periods sit at bits 16.., even ones at bits 1..: qbit)
+    const uint32_t clean = ~sc.settled;
+    const uint32_t vo = 2u * (uint32_t)__builtin_ctz(((clean >> 16) & 0xfu) | 0x10u) + 1u, ve = 2u * (uint32_t)__builtin_ctz(((clean >> 1) & 0xfu) | 0x10u) + 2u;
+    const uint32_t v = vo < ve ? vo : ve;
+    sc.vp = v <= 8u ? v : 0u;
 }
 
 // exact ends of the candidates, clean-up, table row
@@ -466,13 +483,14 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
     const uint64_t wave = (uint64_t)blockIdx.x * wpb + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = (uint64_t)gridDim.x * wpb;
     const uint64_t total16 = (offsets[n] + 15u) & ~(uint64_t)15;        // the batch is readable below this offset
     const uint64_t ymax = total16 - 8u;
-    for (uint64_t turn = wave; turn < n; turn += n_waves) {
-        // Which string a wave takes is rotated within blocks of 64 by an amount that changes from block to block.  Workgroups go to
-        // the eight XCDs in turn, so in a batch whose strings repeat a pattern of costs with a small period (BASELINE configs[2]: every
-        // fourth string is text of many short runs, 4 x the scalar work) the expensive strings of EVERY round fell to the same XCDs:
-        // 6.8 ms against 3.8 ms for the same batch with two-wave and four-wave workgroups.
-        uint64_t sid = turn;
-        if (rotate && (turn | 63ull) < n) sid = (turn & ~63ull) | ((turn + 17ull * (turn >> 6)) & 63ull);
+    // Which string a wave takes first is rotated within blocks of 64 by an amount that changes from block to block.  Workgroups go to
+    // the eight XCDs in turn, so in a batch whose strings repeat a pattern of costs with a small period (BASELINE configs[2]: every
+    // fourth string is text of many short runs, 4 x the scalar work) the expensive strings of EVERY round fell to the same XCDs:
+    // 6.8 ms against 3.8 ms for the same batch with two-wave and four-wave workgroups.  (A wave's later strings are n_waves apart:
+    // still every string exactly once.)
+    uint64_t first = wave;
+    if (rotate && (wave | 63ull) < n) first = (wave & ~63ull) | ((wave + 17ull * (wave >> 6)) & 63ull);
+    for (uint64_t sid = first; sid < n; sid += n_waves) {
         const uint64_t b = offsets[sid], e = offsets[sid + 1];
         uint64_t* const tab = table + sid * MFA_REGION_WORDS;
         if (e - b > kMaxLen) { if (lane == 0) tab[0] = MFA_REGION_OVERFLOW; continue; }
