@@ -955,6 +955,24 @@ WALK_DEV unsigned long long wv_clock() { return __builtin_readcyclecounter(); }
 #endif
 
 // Feeder::take(want, sid): hands the next string index to every lane that wants one; returns false when the batch is exhausted
+// The probe's small counters in ONE register (they are all alive across the step, where the kernel's register peak is: seven registers
+// less there): phase 0..3 | pk, pp <= 16 | mult 1..8 | fails < 8 | log2 of the back-off (8 .. 4096) | plain periods of the probe (saturating)
+struct ProbeCtl {
+    uint32_t w;
+    WALK_DEV uint32_t get(uint32_t sh, uint32_t bits) const { return (w >> sh) & ((1u << bits) - 1u); }
+    WALK_DEV void put(uint32_t sh, uint32_t bits, uint32_t v) { w = (w & ~(((1u << bits) - 1u) << sh)) | ((v & ((1u << bits) - 1u)) << sh); }
+    WALK_DEV void reset() { w = 0u; set_pp(1u); set_mult(1u); backoff_reset(); }
+    WALK_DEV uint32_t phase() const { return get(0, 2); }   WALK_DEV void set_phase(uint32_t v) { put(0, 2, v); }
+    WALK_DEV uint32_t pk() const { return get(2, 5); }      WALK_DEV void set_pk(uint32_t v) { put(2, 5, v); }      WALK_DEV void inc_pk() { set_pk(pk() + 1u); }
+    WALK_DEV uint32_t pp() const { return get(7, 5); }      WALK_DEV void set_pp(uint32_t v) { put(7, 5, v); }
+    WALK_DEV uint32_t mult() const { return get(12, 4); }   WALK_DEV void set_mult(uint32_t v) { put(12, 4, v); }
+    WALK_DEV uint32_t fails() const { return get(16, 4); }  WALK_DEV void set_fails(uint32_t v) { put(16, 4, v); }  WALK_DEV void inc_fails() { set_fails(fails() + 1u); }
+    WALK_DEV uint32_t backoff() const { return 1u << get(20, 4); }
+    WALK_DEV void backoff_reset() { put(20, 4, 3u); }
+    WALK_DEV void backoff_double() { const uint32_t l = get(20, 4); put(20, 4, l < 12u ? l + 1u : l); }
+    WALK_DEV uint32_t nper() const { return get(24, 8); }   WALK_DEV void set_nper(uint32_t v) { put(24, 8, v); }   WALK_DEV void inc_nper() { const uint32_t n = nper(); set_nper(n < 255u ? n + 1u : n); }
+};
+
 template <int K, bool REV, class Feeder, class TP>
 WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t* rt_cache, Feeder& feed, WaveStats* stats) {
     WIn in;
@@ -963,8 +981,11 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
     in.w0 = in.w1 = in.w2 = in.w3 = 0;
     bool active = false, exhausted = false, accept = false;
     uint32_t i = 0, len = 0; uint64_t sid = 0;
+    // probes: P.phase() 0 idle, 1 = plain periods after saving the list, 2 = the dual period
     // probes: phase 0 idle, 1 = plain periods after saving the list, 2 = the dual period
-    uint32_t phase = 0, probe_at = 0, backoff = 8, pp = 1, pk = 0, fails = 0, mult = 1, nper = 0;
+    uint32_t probe_at = 0;
+    ProbeCtl P;
+    P.reset();
     tb_t TBacc = tb_init();
     bool fits = true, stable = false, patient = false;
     uint32_t cur = 0, n_cur = 0, sb_n = 0, warm = 0;
@@ -998,7 +1019,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                             for (uint32_t k = 1; k < b.n_seg; k++)
                                 if (sid >= b.seg_first[k]) seg = k;
                             aut_load(au, T, b.n_seg ? b.seg_table[seg] : 0u);
-                            i = 0; accept = false; active = true; phase = 0; probe_at = 0; backoff = 8; pp = 1; fails = 0; mult = 1; nper = 0;
+                            i = 0; accept = false; active = true; P.set_phase(0); probe_at = 0; P.backoff_reset(); P.set_pp(1); P.set_fails(0); P.set_mult(1); P.set_nper(0);
                             stable = false; patient = false;
                             n_cur = 1;                                // the list: (pos 0, start, no cells)  mfa.cpp:217-219
                             Ent<uint32_t, K> e0;
@@ -1021,29 +1042,29 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
         WALK_LAP(t_byte);
         // ---- does this lane sit at the start of a stretch that repeats?  (probes run in epochs: all lanes that probe do it together)
         uint32_t q = 0u;
-        const bool ep_busy = __any(phase != 0u);
-        if (b.accel && active && !final_pass && phase == 0u && i >= probe_at && !ep_busy) {
+        const bool ep_busy = __any(P.phase() != 0u);
+        if (b.accel && active && !final_pass && P.phase() == 0u && i >= probe_at && !ep_busy) {
             if (in.per_q != 0u && in.per_lo <= i && i < in.per_hi) q = in.per_q;      // still inside the region found last
             else if (in.regions != nullptr) {
                 uint32_t rl, rh, rq, rn;
-                if (w_rt_find<REV>(in, i, mult, rl, rh, rq, rn)) {
+                if (w_rt_find<REV>(in, i, P.mult(), rl, rh, rq, rn)) {
                     if (in.per_q != 0u) { in.prev_lo = in.per_lo; in.prev_hi = in.per_hi; in.prev_q = in.per_q; }
                     in.per_lo = rl; in.per_hi = rh; in.per_q = rq; q = rq;
                 } else probe_at = rn;                                        // look again where the next region starts (never, if there is none)
             } else probe_at = ~0u;                                           // no table: every step is executed
         }
         if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }
-        if (q != 0u && q * mult > 16u) mult = 1u;
-        const unsigned long long cand = __ballot(q != 0u && in.per_hi - i >= 4u * q * mult + 24u);
-        const uint32_t ep_pp = cand ? __shfl(q * mult, __builtin_ctzll(cand)) : 0u;      // the first candidate's period leads the epoch
+        if (q != 0u && q * P.mult() > 16u) P.set_mult(1u);
+        const unsigned long long cand = __ballot(q != 0u && in.per_hi - i >= 4u * q * P.mult() + 24u);
+        const uint32_t ep_pp = cand ? __shfl(q * P.mult(), __builtin_ctzll(cand)) : 0u;      // the first candidate's period leads the epoch
         {
             bool begin = false;
             if (q != 0u) {
-                pp = ep_pp;
-                if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * pp + 24u) {
-                    begin = true; phase = 1u; pk = 0u; nper = 0u; stable = false; sb_n = n_cur;
+                P.set_pp(ep_pp);
+                if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * P.pp() + 24u) {
+                    begin = true; P.set_phase(1u); P.set_pk(0u); P.set_nper(0u); stable = false; sb_n = n_cur;
                     if (stats) stats->probes++;
-                } else if (in.per_hi - i < 4u * q * mult + 24u) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // too short to be worth a probe
+                } else if (in.per_hi - i < 4u * q * P.mult() + 24u) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // too short to be worth a probe
                 else probe_at = i + 1u;                                                                                  // does not fit this epoch's period
             }
             if (__any(begin)) image_save<K>(st, cur, begin, n_cur);
@@ -1051,7 +1072,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
         WALK_LAP(t_look);
         uint32_t n_next = 0;
         tb_t TB = tb_init();
-        const bool p2 = phase == 2u;
+        const bool p2 = P.phase() == 2u;
         const bool accept_before = accept, fits_before = fits;
         in.cq_n = 0u;
         for (;;) {                                                   // (again after the wave has answered what the step asked for)
@@ -1059,8 +1080,8 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
             if (WALK_WITH_DUAL && __any(p2)) {
                 // dual step: lanes in their dual period carry the list's directions, the others direction 0 (their TB is ignored)
                 if (stats) stats->dual++;
-                const Dual di{i, (int32_t)pp}, dlen{len, 0};
-                in.dual_p = p2 ? pp : 0u;
+                const Dual di{i, (int32_t)P.pp()}, dlen{len, 0};
+                in.dual_p = p2 ? P.pp() : 0u;
                 (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the region
                 (void)eq(di, dlen, TB);
                 walk_step<Dual, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB);
@@ -1084,78 +1105,78 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
         uint32_t skip = 0;
         if (p2) {
             tb_min(TBacc, TB.a, TB.b);
-            pk++;
+            P.inc_pk();
             bool ended = false;
-            if (pk == pp) {
+            if (P.pk() == P.pp()) {
                 const int64_t periods = tb_steps(TBacc);
                 bool same = !accept && any_next && periods > 1 && fits;
                 ended = true;
                 // (the comparison below is wave-level code: done after this block)
                 if (!same) ended = true;
-                phase = same ? 3u : 0u;                              // 3: the comparison with the image decides
+                P.set_phase(same ? 3u : 0u);                              // 3: the comparison with the image decides
             } else if (tb_is_one(TBacc) || accept || !any_next) {
-                phase = 0u; fails++;                                 // cannot succeed any more: stop the probe here
-                if (nper == 1u && !patient && pp > 2u) patient = true; else mult = mult % 8u + 1u;
-                if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }
+                P.set_phase(0u); P.inc_fails();                                 // cannot succeed any more: stop the probe here
+                if (P.nper() == 1u && !patient && P.pp() > 2u) patient = true; else P.set_mult(P.mult() % 8u + 1u);
+                if (P.fails() >= 8u) { P.set_fails(0u); P.backoff_double(); }
             }
             (void)ended;
         }
-        if (__any(phase == 3u)) {
-            const bool same = image_same<K>(st, cur, phase == 3u, n_cur, sb_n);
-            if (phase == 3u) {
+        if (__any(P.phase() == 3u)) {
+            const bool same = image_same<K>(st, cur, P.phase() == 3u, n_cur, sb_n);
+            if (P.phase() == 3u) {
                 if (same) {
                     const int64_t periods = tb_steps(TBacc);
                     skip = (uint32_t)(periods - 1 < (int64_t)0x00ffffff ? periods - 1 : (int64_t)0x00ffffff);
                 }
-                phase = 0u;
+                P.set_phase(0u);
             }
         }
-        if (p2 && pk == pp && phase == 0u) {
-            if (skip) { backoff = 8u; fails = 0u; if (stats) { stats->hits++; stats->skipped += (unsigned long long)skip * pp; } }
+        if (p2 && P.pk() == P.pp() && P.phase() == 0u) {
+            if (skip) { P.backoff_reset(); P.set_fails(0u); if (stats) { stats->hits++; stats->skipped += (unsigned long long)skip * P.pp(); } }
             else {
                 // a failed dual period: after an optimistic start (one plain period) the next probe of this string waits for two equal
                 // movements; otherwise the list may repeat with a multiple of the period
-                fails++;
-                if (nper == 1u && !patient && pp > 2u) patient = true; else mult = mult % 8u + 1u;
-                if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }
+                P.inc_fails();
+                if (P.nper() == 1u && !patient && P.pp() > 2u) patient = true; else P.set_mult(P.mult() % 8u + 1u);
+                if (P.fails() >= 8u) { P.set_fails(0u); P.backoff_double(); }
             }
         }
         if (__any(skip != 0u)) image_advance<K>(st, cur, skip != 0u, n_cur, skip);
-        if (skip) { i += skip * pp; w_drop_window(in); probe_at = i + 1u + pp; }
-        else if (p2 && phase == 0u) probe_at = i + (fails ? 1u : backoff);
-        if (phase == 1u) pk++;
+        if (skip) { i += skip * P.pp(); w_drop_window(in); probe_at = i + 1u + P.pp(); }
+        else if (p2 && P.phase() == 0u) probe_at = i + (P.fails() ? 1u : P.backoff());
+        if (P.phase() == 1u) P.inc_pk();
         // plain periods of a probe: after each one the movement of the list over the period is compared with the previous period's; a
         // lane is ready for the dual period once two consecutive movements agree.  All lanes of an epoch reach their period
         // boundaries in the same iteration and go on together.
         {
-            const bool at_end = phase == 1u && pk == pp;
+            const bool at_end = P.phase() == 1u && P.pk() == P.pp();
             if (__any(at_end)) {
                 bool moved, wide, vac;
                 image_measure<K>(st, cur, at_end, n_cur, sb_n, moved, wide, vac);
                 if (at_end) {
-                    const bool eqd = nper != 0u && !moved;
-                    const bool occ = nper == 0u && !patient && pp > 2u && !vac;      // first period: the same nodes before and after it
+                    const bool eqd = P.nper() != 0u && !moved;
+                    const bool occ = P.nper() == 0u && !patient && P.pp() > 2u && !vac;      // first period: the same nodes before and after it
                     fits = !wide;
                     sb_n = n_cur;
-                    nper++; pk = 0u; stable = (eqd || occ) && fits;
+                    P.inc_nper(); P.set_pk(0u); stable = (eqd || occ) && fits;
                 }
             }
         }
         {
-            const bool at_b = phase == 1u && pk == 0u && nper != 0u;
+            const bool at_b = P.phase() == 1u && P.pk() == 0u && P.nper() != 0u;
             if (__any(at_b)) {
-                const bool room = in.per_hi >= i + 1u + 2u * pp;      // the dual period and at least one more to skip
-                if (!__any(at_b && !stable && room && nper < (pp > 2u ? WALK_PROBE_PERIODS : 3u))) {
+                const bool room = in.per_hi >= i + 1u + 2u * P.pp();      // the dual period and at least one more to skip
+                if (!__any(at_b && !stable && room && P.nper() < (P.pp() > 2u ? WALK_PROBE_PERIODS : 3u))) {
                     const bool go = at_b && stable && room;
                     if (__any(go)) image_dirs<K>(st, cur, go, n_cur);
-                    if (go) { phase = 2u; TBacc = tb_init(); pk = 0u; }
+                    if (go) { P.set_phase(2u); TBacc = tb_init(); P.set_pk(0u); }
                     else if (at_b) {
-                        phase = 0u;
+                        P.set_phase(0u);
                         if (!room) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;
                         else {                                        // never settled: maybe the list repeats with a multiple of the period
-                            fails++; mult = mult % 8u + 1u;
-                            if (fails >= 8u) { fails = 0u; backoff = backoff < 4096u ? backoff * 2u : backoff; }
-                            probe_at = i + 1u + (fails ? 0u : backoff);
+                            P.inc_fails(); P.set_mult(P.mult() % 8u + 1u);
+                            if (P.fails() >= 8u) { P.set_fails(0u); P.backoff_double(); }
+                            probe_at = i + 1u + (P.fails() ? 0u : P.backoff());
                         }
                     }
                 }
@@ -1167,7 +1188,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
             if (stats) stats->steps++;
             if (done) {
                 b.results[sid] = (warm == 0x9e3779b9u && len == 0xffffffffu) ? 3 : (accept ? 1 : 0);      // (warm keeps the touches alive)
-                active = false; phase = 0u; n_cur = 0u;
+                active = false; P.set_phase(0u); n_cur = 0u;
                 if (stats) stats->strings++;
             }
         }
