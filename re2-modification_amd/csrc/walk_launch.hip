@@ -228,7 +228,8 @@ static int mixed_device(mfa_mixed* mx, int device, mfa_mixed::Dev** out) {
     }
     HIP_TRY(hipMalloc((void**)&d.d_counters, 64 * MIX_MAX_LAUNCHES * sizeof(unsigned long long)));
     HIP_TRY(hipStreamCreateWithFlags(&d.rs, hipStreamNonBlocking));
-    for (hipStream_t& w : d.ws) HIP_TRY(hipStreamCreateWithFlags(&w, hipStreamNonBlocking));
+    // Streams are made when a call first needs them (walk_stream / region_stream2): every stream beyond the hardware queues of the process (four
+    // by default, the caller's included) shares a queue with another one, and work on streams that share a queue is serialised
     for (hipEvent_t& e : d.ev_g) HIP_TRY(hipEventCreate(&e));
     for (hipEvent_t& e : d.ev_w) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.ev_in, hipEventDisableTiming));
@@ -297,18 +298,27 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
     }
     HIP_TRY(hipEventRecord(d->ev_in, cs));
     HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_in, 0));
-    for (int k = 0; k < NW; k++) HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_in, 0));
+    for (int k = 0; k < NW; k++) {
+        if (!d->ws[k]) {
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            if (env_int("MFA_MIXED_WALK_PRIORITY", 0) != 0) HIP_TRY(hipStreamCreateWithPriority(&d->ws[k], hipStreamNonBlocking, greatest));
+            else HIP_TRY(hipStreamCreateWithFlags(&d->ws[k], hipStreamNonBlocking));
+        }
+        HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_in, 0));
+    }
     const uint32_t slot_t = (uint32_t)(d->calls % MIX_TIMINGS);
     HIP_TRY(hipEventRecord(d->ev_r0[slot_t], d->rs));
     bool used[MIX_MAX_STREAMS] = {false};
     uint32_t slot = 0;                                        // table engine: launches of this call
     for (uint32_t g = 0; g < ng; g++) {
         const uint64_t lo = cut[g], hi = cut[g + 1];
+        hipStream_t rg = d->rs;
         if (with_regions) {
-            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d->d_regions + lo * MFA_REGION_WORDS, d->rs, table ? 128u : 256u);
+            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d->d_regions + lo * MFA_REGION_WORDS, rg, table ? 128u : 256u);
             if (rc != MFA_OK) return rc;
         }
-        HIP_TRY(hipEventRecord(d->ev_g[g], d->rs));
+        HIP_TRY(hipEventRecord(d->ev_g[g], rg));
         const uint64_t* tab = with_regions ? d->d_regions : nullptr;
         // the segments that overlap this group
         uint32_t sa = 0;
