@@ -59,3 +59,24 @@ def test_no_cpu_fallback():
     with pytest.raises(capi.MfaError) as e:
         img.match_host(data, off)
     assert e.value.code == capi.ERR_NO_DEVICE
+
+
+def test_register_budget_of_the_built_kernels():
+    """The region pass shares SIMDs with walk waves (512 VGPRs each): its streaming kernel must stay within 40 VGPRs (an allocation of 40,
+    not 48) and the one-cell walk within 168, or one region wave fewer fits beside two walk waves.  Read from the build's own resource
+    remarks (csrc/Makefile keeps them and fails the build on the first of the two)."""
+    import re
+    csrc = os.path.join(os.path.dirname(capi.LIB_PATH))
+    def vgprs(log, name_part):
+        text = open(os.path.join(csrc, log)).read()
+        out = []
+        for m in re.finditer(r"Function Name: (\S+).*?\n(?:.*\n)*?.*? VGPRs: (\d+)", text):
+            if name_part in m.group(1):
+                out.append(int(m.group(2)))
+        return out
+    if not os.path.exists(os.path.join(csrc, "regions.log")):
+        pytest.skip("library built without the resource remarks")
+    region = vgprs("regions.log", "region_scan_kernelILi0ELi2ELb0E")
+    assert region and max(region) <= 40, region
+    walk1 = vgprs("walk_k1.log", "walk_kernelILi1E")
+    assert walk1 and max(walk1) <= 168, walk1
