@@ -311,19 +311,20 @@ WALK_DEV bool w_read_pre(WIn& in, U i, uint32_t ch, U start, U l, uint32_t fl, t
 }
 
 // ---- per-lane view of an automaton's tables ------------------------------------------------------------------------------------
-struct Aut {                 // three registers per lane: where the automaton's table block starts, and its two dimensions
-    uint32_t at, nv, dims;   // dims = classes | variant bits << 8
+struct Aut {                 // two registers per lane: where the automaton's table block starts, and its dimensions
+    uint32_t at, dims;       // dims = classes | variant bits << 8 | vnodes << 12   (at most 255 classes, 13 variant bits, 2^13 vnodes)
     WALK_DEV uint32_t nc() const { return dims & 0xffu; }
-    WALK_DEV uint32_t vbits() const { return dims >> 8; }
+    WALK_DEV uint32_t vbits() const { return (dims >> 8) & 0xfu; }
+    WALK_DEV uint32_t nv() const { return dims >> 12; }
     // the block's layout is fixed (walk_tables.cpp): header, class map, vinfo[nv], vc[nv], vb[nv][nc], effective edges
     WALK_DEV uint32_t cmap() const { return at + 16u; }
     WALK_DEV uint32_t vinfo() const { return at + 80u; }
-    WALK_DEV uint32_t vc() const { return at + 80u + nv; }
-    WALK_DEV uint32_t vb() const { return at + 80u + 2u * nv; }
-    WALK_DEV uint32_t ee() const { return at + 80u + nv * (2u + nc()); }
+    WALK_DEV uint32_t vc() const { return at + 80u + nv(); }
+    WALK_DEV uint32_t vb() const { return at + 80u + 2u * nv(); }
+    WALK_DEV uint32_t ee() const { return at + 80u + nv() * (2u + nc()); }
 };
 template <class TP> WALK_DEV void aut_load(Aut& a, TP T, uint32_t at) {
-    a.at = at; a.nv = T[at]; a.dims = T[at + 2] | (T[at + 1] << 8);
+    a.at = at; a.dims = T[at + 2] | (T[at + 1] << 8) | (T[at] << 12);
 }
 template <class TP> WALK_DEV uint32_t aut_start(TP T, const Aut& a) { return T[a.at + 4]; }
 
@@ -980,7 +981,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
     w_reset(in, 0, 0, 0);
     in.w0 = in.w1 = in.w2 = in.w3 = 0;
     bool active = false, exhausted = false, accept = false;
-    uint32_t i = 0, len = 0; uint64_t sid = 0;
+    uint32_t i = 0, len = 0;      // (the string's number is in.sid: a launch holds fewer than 2^32 strings)
     // probes: P.phase() 0 idle, 1 = plain periods after saving the list, 2 = the dual period
     // probes: phase 0 idle, 1 = plain periods after saving the list, 2 = the dual period
     uint32_t probe_at = 0;
@@ -1006,7 +1007,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                 if (want) {
                     if (!got) exhausted = true;
                     else {
-                        sid = s;
+                        const uint64_t sid = s;
                         uint4 rta, rtb;
                         rt_fetch(b.regions, sid, rta, rtb);          // the table row and the offsets travel together
                         const uint64_t o0 = b.offsets[sid], o1 = b.offsets[sid + 1];
@@ -1187,7 +1188,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
             i++;
             if (stats) stats->steps++;
             if (done) {
-                b.results[sid] = (warm == 0x9e3779b9u && len == 0xffffffffu) ? 3 : (accept ? 1 : 0);      // (warm keeps the touches alive)
+                b.results[in.sid] = (warm == 0x9e3779b9u && len == 0xffffffffu) ? 3 : (accept ? 1 : 0);      // (warm keeps the touches alive)
                 active = false; P.set_phase(0u); n_cur = 0u;
                 if (stats) stats->strings++;
             }
