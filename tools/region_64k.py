@@ -32,6 +32,8 @@ def run(kind, length):
     print("%-7s length %6d x %d: %.3f ms = %.0f GB/s" % (kind, length, n, ms, n * length / ms / 1e6), flush=True)
     del flat, data, off, tab
 
-for kind in ("all_a", "last_b", "one_b", "noise"):
-    for length in (65536, 65536 + 192, 65536 - 1000):
+kinds = [os.environ["ONLY_KIND"]] if os.environ.get("ONLY_KIND") else ["all_a", "last_b", "one_b", "noise"]
+lengths = [int(os.environ["ONLY_LEN"])] if os.environ.get("ONLY_LEN") else [65536, 65536 + 192, 65536 - 1000]
+for kind in kinds:
+    for length in lengths:
         run(kind, length)
