@@ -342,16 +342,20 @@ __device__ __forceinline__ void scan_row(Scan& sc, uint32_t lane, const Geo& g, 
     // Rows of runs of one byte broken by other bytes (thousands per string in text of that kind, and the rows where a run of the attack
     // corpus ends): every block that is dirty for period 1 is dirty for all periods, and no period's clean stretch reaches further back
     // than period 1's -- row_inside<Q, 1> for the seven other periods, decided before any of them does its book-keeping: they only
-    // note their last dirty block.  (The ballots are taken again on the other path: keeping all eight alive spilled scalar registers.)
-    bool inside = rb.dirty[1] != 0ull;
-    int32_t nl[9];
-#define MFA_TRY_INSIDE(Q) { const int32_t bq = (was & qbit(Q)) ? base - 1 : st.last_dirty[Q]; const unsigned long long dq = __ballot((mask & qbit(Q)) != 0u); \
-                            inside = inside && (rb.dirty[1] & ~dq) == 0ull && bq >= rb.before[1]; nl[Q] = base + 63 - (int32_t)__builtin_clzll(dq | 1ull); }
-    MFA_TRY_INSIDE(2) MFA_TRY_INSIDE(3) MFA_TRY_INSIDE(4) MFA_TRY_INSIDE(5) MFA_TRY_INSIDE(6) MFA_TRY_INSIDE(7) MFA_TRY_INSIDE(8)
-#undef MFA_TRY_INSIDE
+    // note a last dirty block.
+    // (one vector test instead of seven ballots: a block that is dirty for period 1 and clean for some other period)
+    bool inside = rb.dirty[1] != 0ull && !__any((mask & qbit(1)) != 0u && mask != kAllDirty);
     if (inside) {
+        int32_t least = 0x7fffffff;
 #pragma unroll
-        for (int q = 2; q <= 8; q++) st.last_dirty[q] = nl[q];
+        for (int q = 2; q <= 8; q++) { const int32_t bq = (was & qbit(q)) ? base - 1 : st.last_dirty[q]; least = bq < least ? bq : least; }
+        inside = least >= rb.before[1];
+    }
+    if (inside) {
+        // where their last dirty block lies inside this row does not matter: every clean block of theirs is clean for period 1, whose
+        // candidates say more -- the end of the row is a safe (late) answer
+#pragma unroll
+        for (int q = 2; q <= 8; q++) st.last_dirty[q] = base + 63;
     } else {
         row_prep<2>(st, mask, was, base, rb); row_period<2>(st, lane, base, rb);
         row_prep<3>(st, mask, was, base, rb); row_period<3>(st, lane, base, rb);
