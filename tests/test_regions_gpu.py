@@ -160,6 +160,20 @@ def test_counted_waits_against_full_waits(monkeypatch):
         assert np.array_equal(fast[k, :1 + cnt], safe[k, :1 + cnt]), k
 
 
+def test_rotated_assignment_changes_nothing(monkeypatch):
+    """Which wave scans which string is rotated within blocks of 64 (so that a cost pattern with a small period in the batch does not fall to
+    the same XCDs); every string must still be scanned exactly once, with the same table as when wave w takes string w."""
+    rng = np.random.default_rng(778)
+    strings = _fuzz_strings(rng, 64 * 9 + 17, 5000)          # nine whole blocks of 64 and a ragged one
+    rotated = scan(strings, 1)
+    monkeypatch.setenv("MFA_REGION_ROTATE", "0")
+    plain = scan(strings, 1)
+    assert np.array_equal(rotated[:, 0], plain[:, 0])
+    for k in range(len(strings)):
+        cnt = int(plain[k, 0]) & 0xff
+        assert np.array_equal(rotated[k, :1 + cnt], plain[k, :1 + cnt]), k
+
+
 @pytest.mark.parametrize("pad", [0, 5, 15])
 def test_region_tables(pad):
     rng = np.random.default_rng(4242 + pad)
