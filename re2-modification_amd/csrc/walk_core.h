@@ -666,17 +666,20 @@ template <class U, int K>
 WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits, U P, uint32_t tie, Ent<U, K>& t) {
     const uint32_t node = vid >> vbits;
     if (pred) WALK_EV(2);
-    uint32_t at = ~0u, old_tie = 0u;
+    uint32_t at = ~0u, old_id = 0u;
     U old = konst<U>(0u);
     constexpr uint32_t NK = KeyCache<U>::N;
+    // (slots the list has not reached hold node 0xffff, which no automaton has; lanes outside `pred` find whatever they find: every use of
+    // `at` below asks for pred)
 #pragma unroll
     for (uint32_t k = 0; k < (NK < 4u ? NK : 4u); k++)
-        if (pred && k < cx.n_next && (cx.keys.id[k] & 0xffffu) == node) { at = k; old_tie = cx.keys.id[k] >> 16; setv(old, cx.keys.P[k]); }
+        if ((cx.keys.id[k] & 0xffffu) == node) { at = k; old_id = cx.keys.id[k]; setv(old, cx.keys.P[k]); }
     if (NK > 4u && __any(pred && at == ~0u && cx.n_next > 4u)) {      // (lists of the README automata never get here)
 #pragma unroll
         for (uint32_t k = 4; k < NK; k++)
-            if (pred && k < cx.n_next && (cx.keys.id[k] & 0xffffu) == node) { at = k; old_tie = cx.keys.id[k] >> 16; setv(old, cx.keys.P[k]); }
+            if ((cx.keys.id[k] & 0xffffu) == node) { at = k; old_id = cx.keys.id[k]; setv(old, cx.keys.P[k]); }
     }
+    uint32_t old_tie = old_id >> 16;
     const bool maybe = NK == 0u || ((cx.keys.seen >> (node & 63u)) & 1ull) != 0ull;
     if (__any(pred && maybe && at == ~0u && cx.n_next > NK)) {          // longer lists: look through the rest
         for (uint32_t j = NK; __any(pred && maybe && at == ~0u && j < cx.n_next); j++) {
@@ -737,6 +740,8 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
                         bool& accept, bool& fits, tb_t& TB) {
     StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB, {}};
     cx.keys.seen = 0ull;
+#pragma unroll
+    for (uint32_t k = 0; k < KeyCache<U>::N; k++) cx.keys.id[k] = 0xffffffffu;
     const uint32_t cls = (active && !final_pass) ? (T[au.cmap() + ((ch & 0xffu) >> 2)] >> (8u * (ch & 3u))) & 0xffu : 0u;
     for (uint32_t e = 0; __any(active && e < n_cur); e++) {
         const bool have = active && e < n_cur;
