@@ -680,11 +680,11 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
             if ((cx.keys.id[k] & 0xffffu) == node) { at = k; old_id = cx.keys.id[k]; setv(old, cx.keys.P[k]); }
     }
     uint32_t old_tie = old_id >> 16;
-    const bool maybe = NK == 0u || ((cx.keys.seen >> (node & 63u)) & 1ull) != 0ull;
-    if (__any(pred && maybe && at == ~0u && cx.n_next > NK)) {          // longer lists: look through the rest
-        for (uint32_t j = NK; __any(pred && maybe && at == ~0u && j < cx.n_next); j++) {
+    if (__any(pred && at == ~0u && cx.n_next > NK)) {                   // longer lists: look through the rest (the filter only knows the entries behind the keys)
+        const bool maybe = pred && at == ~0u && (NK == 0u || ((cx.keys.seen >> (node & 63u)) & 1ull) != 0ull);
+        for (uint32_t j = NK; __any(maybe && at == ~0u && j < cx.n_next); j++) {
             WALK_EV(3);
-            const bool look = pred && maybe && at == ~0u && j < cx.n_next;
+            const bool look = maybe && at == ~0u && j < cx.n_next;
             const uint32_t x = look ? rd_v<K>(cx.st, cx.nxt, j, 1) : 0u;
             if (look && ((x & 0xffffu) >> vbits) == node) { at = j; old_tie = x >> 16; setv(old, rd_v<K>(cx.st, cx.nxt, j, 0)); }
         }
@@ -694,8 +694,11 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
         load_pdir<K>(cx.st, cx.nxt, at, cx.dual_lane, old);
         win = lt(P, old, cx.TB) || (eq(P, old, cx.TB) && tie < old_tie);
     }
+    if (NK != 0u && __any(win && at == ~0u && cx.n_next >= NK)) {       // an entry behind the keys: the filter learns its node
+        if (win && at == ~0u && cx.n_next >= NK) cx.keys.seen |= 1ull << (node & 63u);
+    }
     if (win) {
-        if (at == ~0u) { at = cx.n_next++; cx.keys.seen |= 1ull << (node & 63u); }
+        if (at == ~0u) at = cx.n_next++;
         t.P = P; t.vid = vid;
         store_entry<U, K>(cx.st, cx.nxt, at, t, tie, cx.fits);
 #pragma unroll
