@@ -461,6 +461,20 @@ def secondary_config5(device, capi, corpus, n_strings=125000):
             res = torch.empty(n, dtype=torch.uint8, device=device)
             t, tr = _timed(img, flat, off, res, device, reps=2)
             nbytes = int(off[-1].item())
+            # the same batch through mfa_match_mixed (one image): the walks of a group of strings beside the region pass of the next
+            mx = capi.Mixed([img])
+            res_m = torch.empty(n, dtype=torch.uint8, device=device)
+            spans = []
+            for _ in range(3):
+                mx.match_tensors(flat, off, [0, n], res_m); torch.cuda.synchronize()
+                spans.append(mx.last_ms(device.index or 0)[1])
+            span = float(np.mean(spans[1:]))
+            mixed = {"kernel": "mfa_match_mixed: region_scan_kernel + " + KERNEL_NAMES.get(img.info()["last_kernel"], "?"), "span_ms": span,
+                     "GB/s": nbytes / (span * 1e-3) / 1e9, "frac_of_hbm_peak_on_touched_bytes": nbytes / (span * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "results_equal": bool(torch.equal(res, res_m))}
+            mx.close()
+            del res_m
+            img.match_tensors(flat, off, res)          # (the per-image engine again: the kernel name reported below)
             rng = np.random.Generator(np.random.Philox(0x5EED0015 + ex))
             idx = np.sort(rng.choice(n, size=max(4, n // 100), replace=False))
             par = parity_sample([(blob, corpus.host_strings(ex, sizes[idx], ws[idx]), res[torch.from_numpy(idx).to(device)].cpu().numpy())])
@@ -468,7 +482,7 @@ def secondary_config5(device, capi, corpus, n_strings=125000):
                         "kernel": "region_scan_kernel + " + KERNEL_NAMES.get(img.info()["last_kernel"], "?"),
                         "region_ms": tr, "walk_ms": t, "GB/s": nbytes / ((t + tr) * 1e-3) / 1e9,
                         "touched_bytes": nbytes, "touched_by": "region pass reads every byte; the walk may exit early",
-                        "frac_of_hbm_peak_on_touched_bytes": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_of_hbm_peak_on_touched_bytes": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS, "mixed_call": mixed,
                         "accepted": int(res.sum().item()), "parity_sample": par})
             del flat, off, res
     return out

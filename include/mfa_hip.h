@@ -141,7 +141,10 @@ typedef struct mfa_mixed mfa_mixed_t;
 int  mfa_mixed_create(mfa_image_t* const* images, uint32_t n_images, mfa_mixed_t** out);
 void mfa_mixed_destroy(mfa_mixed_t* mx);
 /* seg_first: HOST array of n_images + 1 string indices, seg_first[0] = 0, seg_first[n_images] = n: strings
- * seg_first[s] .. seg_first[s+1]-1 are matched against images[s].  Device pointers as in mfa_match_batch. */
+ * seg_first[s] .. seg_first[s+1]-1 are matched against images[s].  Device pointers as in mfa_match_batch.
+ * Asynchronous on `stream` -- except that the first call with a string count this object has not met (n >= 65536) reads the
+ * batch's size in bytes back (offsets[n] - offsets[0]) to choose the number of groups, and waits for `stream` to do so
+ * (make such a call outside a stream capture). */
 int  mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                      const uint64_t* seg_first, uint8_t* d_results, int device, void* stream);
 /* the same with HOST pointers (copy in, match, copy out, synchronise): for callers that hold std::strings */

@@ -5,7 +5,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <new>
+#include <string>
+#include <vector>
 
 #include "mfa_internal.h"
 #include "walk.h"
@@ -135,6 +138,7 @@ struct mfa_mixed {
     uint32_t K = 1, max_live = 1;
     bool reversed = false, table_ok = true;
     std::mutex mu;
+    std::map<uint64_t, uint64_t> bytes_of;                     // string count of a batch -> its bytes (read back once, see mfa_match_mixed)
     struct Dev {
         uint32_t* d_tables = nullptr;
         hipStream_t rs = nullptr;                              // region stream
@@ -260,8 +264,41 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
     // last group is what the call ends with.
     std::vector<uint64_t> cut{0};
     {
+        // How many groups pays depends on the batch's BYTES: a group's region launch should take about as long as a walk launch needs anyway
+        // (a walk is latency-bound: ~0.3-0.5 ms for 20 000 strings as for 200 000): 1.3 GB per group, eight groups at most (measured: 10.7 GB of
+        // 64 KiB strings 2.02 ms in eight groups, 2.28 ms in four; the 19.4 GB headline batch eight).  Cut finer, a small batch pays the walks'
+        // latency once per group (a 1.9 GB batch of one automaton: 1.26 ms in eight groups against 0.52 ms in one; 34 ms against 9.8 ms
+        // for the 77-node automaton).  The bytes of a batch are device data (offsets[n] - offsets[0]): they are read back ONCE per string count
+        // this object meets -- that call waits for the caller's stream -- and remembered.
         const char* spec = getenv("MFA_MIXED_CUTS");
-        if (!spec) spec = n < 65536 ? "" : table ? "0.15,0.3,0.45,0.6,0.75,0.87,0.95" : "0.3,0.6,0.8,0.9";
+        std::string made;
+        if (!spec) {
+            uint64_t bytes = 0;
+            auto known = mx->bytes_of.find(n);
+            if (known != mx->bytes_of.end()) bytes = known->second;
+            else if (n >= 65536) {
+                uint64_t ends[2] = {0, 0};
+                HIP_TRY(hipMemcpyAsync(&ends[0], d_offsets, sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+                HIP_TRY(hipMemcpyAsync(&ends[1], d_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
+                HIP_TRY(hipStreamSynchronize(cs));
+                bytes = ends[1] - ends[0];
+                if (mx->bytes_of.size() < 64) mx->bytes_of[n] = bytes;
+            }
+            const double per_group = table ? 1.3e9 : 2.0e9;
+            const uint32_t most = table ? 8u : 5u;
+            uint32_t want = (uint32_t)std::min<double>(most, std::max(1.0, std::floor((double)bytes / per_group + 0.5)));
+            if (n < 65536) want = 1;
+            // sizes: equal, the last three groups 0.8 / 0.53 / 0.33 of that (two groups: 1, 0.6; three: 1, 0.8, 0.4) -- the walk of the last
+            // group is what the call ends with
+            std::vector<double> w(want, 1.0);
+            if (want == 2) w[1] = 0.6;
+            else if (want == 3) { w[1] = 0.8; w[2] = 0.4; }
+            else if (want >= 4) { w[want - 3] = 0.8; w[want - 2] = 0.53; w[want - 1] = 0.33; }
+            double total = 0, acc = 0;
+            for (double x : w) total += x;
+            for (uint32_t k = 0; k + 1 < want; k++) { acc += w[k]; made += (k ? "," : "") + std::to_string(acc / total); }
+            spec = made.c_str();
+        }
         for (const char* q = spec; *q && cut.size() < MIX_MAX_GROUPS;) {
             const uint64_t at = (uint64_t)((double)n * atof(q));
             if (at > cut.back() && at < n) cut.push_back(at);
