@@ -681,7 +681,12 @@ def main():
                 traffic = tj["hbm_bytes_per_step"]
         except (OSError, KeyError, ValueError):
             pass
-        n_groups = len((os.environ.get("MFA_MIXED_CUTS") or ("0.3,0.6,0.8,0.9" if os.environ.get("MFA_WALK", "") == "jit" else "0.15,0.3,0.45,0.6,0.75,0.87,0.95")).split(",")) + 1
+        # the library's rule (walk_launch.hip): MFA_MIXED_CUTS, or one group per 1.3 GB (2 GB with generated kernels) of the batch, 8 (5) at most
+        if os.environ.get("MFA_MIXED_CUTS") is not None:
+            n_groups = len([c for c in os.environ["MFA_MIXED_CUTS"].split(",") if c]) + 1
+        else:
+            jit_engine = os.environ.get("MFA_WALK", "") == "jit"
+            n_groups = 1 if total_strings < 65536 else int(min(5 if jit_engine else 8, max(1, (total_bytes / (2.0e9 if jit_engine else 1.3e9) + 0.5) // 1)))
         out = {
             "metric": "input GB/s (chars matched/sec) on 10-example attack corpus",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
