@@ -610,6 +610,40 @@ def test_mixed_batch_in_one_call(monkeypatch):
         assert np.array_equal(got, want), layout[k]
 
 
+def test_mixed_batch_default_grouping_reads_the_size_once(monkeypatch):
+    """Without MFA_MIXED_CUTS the call chooses its groups from the batch's bytes, which it reads back on the first call with a string
+    count it has not met (waiting for the caller's stream) and remembers: first and second call, on a side stream with work pending, must
+    agree with the single-automaton entry point."""
+    import torch
+    from mfa_amd import corpus
+    monkeypatch.delenv("MFA_MIXED_CUTS", raising=False)
+    dev = torch.device("cuda", 0)
+    n_per = 40000                                             # 80 000 strings: above the 65 536 below which a batch is never cut
+    parts_b, parts_o, seg, pos_b, blobs = [], [], [0], 0, []
+    for ex in (1, 6):
+        sizes = corpus.pump_sizes(n_per, 0x5EED0031 + ex, 64, 3000)
+        b, o = corpus.device_batch(ex, sizes, (np.arange(n_per) % 2) == 0, dev)
+        nb = int(o[-1].item())
+        parts_b.append(b[:nb]); parts_o.append(o[:-1] + pos_b); pos_b += nb; seg.append(seg[-1] + n_per)
+        blobs.append(image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex)))
+    bytes_all = torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=dev)])
+    off_all = torch.cat(parts_o + [torch.tensor([pos_b], dtype=torch.int64, device=dev)])
+    images = [capi.Image(b) for b in blobs]
+    want = torch.cat([images[k].match_tensors(bytes_all, off_all[seg[k]:seg[k + 1] + 1]).clone() for k in range(2)])
+    torch.cuda.synchronize()
+    mx = capi.Mixed(images)
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):
+        busy = torch.zeros(1 << 26, dtype=torch.float32, device=dev)
+        for _ in range(20):
+            busy += 1.0                                        # work the first call has to wait for
+        first = mx.match_tensors(bytes_all, off_all, seg, stream=side).clone()
+        second = mx.match_tensors(bytes_all, off_all, seg, stream=side).clone()
+    side.synchronize()
+    assert torch.equal(first, want) and torch.equal(second, want)
+    mx.close()
+
+
 def test_mixed_batch_corner_cases(tmp_path, monkeypatch):
     """mfa_match_mixed beyond the headline shape: reversed automata in one launch (a launch scans in one direction), an automaton
     with 7 cells among automata with 1-2 (every table of the launch is then read with 3-word edges), an empty segment, and a mix
