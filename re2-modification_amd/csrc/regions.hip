@@ -96,7 +96,6 @@ __device__ __forceinline__ uint32_t block_mask(uint32_t w0, uint32_t w1, uint32_
 
 struct RegionState {
     int32_t  last_dirty[9];      // per period: the last dirty block seen (scalar registers after unrolling)
-    int32_t  cand_x[9], cand_y[9];   // per period: the candidate recorded last
     uint32_t ncand;              // candidates recorded so far (wave-uniform)
     uint32_t shortest;           // with 64 candidates held: the shortest one, length in blocks << 6 | lane (~0u: not known; wave-uniform)
     // candidate e lives in lane e
@@ -125,14 +124,11 @@ __device__ __forceinline__ uint32_t shortest_candidate(const RegionState& st, ui
     return wave_min_u32(lane < kEarly ? 0xffffffc0u | lane : ((uint32_t)(st.cy - st.cx) << 6) | lane);          // length in blocks (< 2^20) | lane
 }
 
-// A candidate of period Q that a candidate of a proper divisor of Q covers (to within a block at either end) is not recorded:
-// the divisor's region says more.  Divisors are handled before Q in every row, so their candidates for the same stretch exist.
+// Records a candidate.  (A candidate that a candidate of a proper divisor covers says nothing new; most of those are never made -- row_same_as,
+// row_inside -- and the others are dropped with the exact ends in hand, finish_string.  Checking here as well kept the last candidate of four
+// periods in eight more scalar registers of a kernel that spills them.)
 template <int Q>
 __device__ __forceinline__ void emit(RegionState& st, uint32_t lane, int32_t x, int32_t y) {
-    st.cand_x[Q] = x; st.cand_y[Q] = y;
-#pragma unroll
-    for (int d = 1; d <= 4; d++)
-        if (d < Q && Q % d == 0 && st.cand_x[d] <= x + 1 && st.cand_y[d] >= y - 1) return;
     if (st.ncand < 64u) {
         if (lane == st.ncand) { st.cq = Q; st.cx = x; st.cy = y; }
         st.ncand++;
@@ -180,10 +176,10 @@ __device__ __forceinline__ bool book(RegionState& st, uint32_t lane, unsigned lo
 
 // One row for one period.  A run of equal bytes is clean for every period, text of period 2 for 4, 6 and 8 as well: where a proper
 // divisor D of Q saw the same dirty blocks in this row and stood at the same block before it, Q's book-keeping would repeat D's
-// step by step and every candidate it found would be dropped as covered by D's (emit) -- D's results are copied instead.  (Rows
+// step by step and every candidate it found would be dropped as covered by D's (finish_string) -- D's position is copied instead.  (Rows
 // at the ends of strings and of regions are the ones that get here; with eight full book-keepings each they were most of the
 // pass's scalar instructions.)
-struct RowBook { unsigned long long dirty[9]; int32_t before[9]; bool emitted[9]; };
+struct RowBook { unsigned long long dirty[9]; int32_t before[9]; };
 
 template <int Q, int D>
 __device__ __forceinline__ bool row_same_as(RegionState& st, RowBook& rb) {
@@ -191,8 +187,6 @@ __device__ __forceinline__ bool row_same_as(RegionState& st, RowBook& rb) {
     else {
         if (rb.dirty[Q] != rb.dirty[D] || rb.before[Q] != rb.before[D]) return false;
         st.last_dirty[Q] = st.last_dirty[D];
-        if (rb.emitted[D]) { st.cand_x[Q] = st.cand_x[D]; st.cand_y[Q] = st.cand_y[D]; }
-        rb.emitted[Q] = rb.emitted[D];
         return true;
     }
 }
@@ -207,7 +201,6 @@ __device__ __forceinline__ bool row_inside(RegionState& st, RowBook& rb, int32_t
     else {
         if ((rb.dirty[D] & ~rb.dirty[Q]) != 0ull || rb.before[Q] < rb.before[D] || rb.dirty[Q] == 0ull) return false;
         st.last_dirty[Q] = base + 63 - (int32_t)__builtin_clzll(rb.dirty[Q]);
-        rb.emitted[Q] = false;
         return true;
     }
 }
@@ -223,7 +216,7 @@ __device__ __forceinline__ void row_period(RegionState& st, uint32_t lane, int32
     if (row_inside<Q, 1>(st, rb, base)) return;
     if (row_same_as<Q, 4>(st, rb) || row_same_as<Q, 3>(st, rb) || row_same_as<Q, 2>(st, rb) || row_same_as<Q, 1>(st, rb)) return;
     if (row_inside<Q, 2>(st, rb, base) || row_inside<Q, 3>(st, rb, base) || row_inside<Q, 4>(st, rb, base)) return;
-    rb.emitted[Q] = book<Q>(st, lane, rb.dirty[Q], base);
+    (void)book<Q>(st, lane, rb.dirty[Q], base);
 }
 // ---- one string ---------------------------------------------------------------------------------------------
 struct Geo {                 // where a string lies: blocks are the 16-byte aligned blocks of the batch it touches
@@ -256,7 +249,7 @@ struct Scan {
 
 __device__ __forceinline__ void scan_reset(Scan& sc) {
 #pragma unroll
-    for (int q = 0; q < 9; q++) { sc.st.last_dirty[q] = -1; sc.st.cand_x[q] = 0x7fffffff; sc.st.cand_y[q] = -1; }
+    for (int q = 0; q < 9; q++) sc.st.last_dirty[q] = -1;
     sc.st.ncand = 0; sc.st.shortest = ~0u; sc.st.cq = 0; sc.st.cx = 0; sc.st.cy = 0;
     sc.settled = ~0u; sc.vp = 0u;
 }
@@ -338,7 +331,7 @@ __device__ __forceinline__ void scan_row(Scan& sc, uint32_t lane, const Geo& g, 
     const uint32_t was = sc.settled != ~0u ? sc.settled : 0u;
     RowBook rb;
     row_prep<1>(st, mask, was, base, rb);
-    rb.emitted[1] = book<1>(st, lane, rb.dirty[1], base);
+    (void)book<1>(st, lane, rb.dirty[1], base);
     // Rows of runs of one byte broken by other bytes (thousands per string in text of that kind, and the rows where a run of the attack
     // corpus ends): every block that is dirty for period 1 is dirty for all periods, and no period's clean stretch reaches further back
     // than period 1's -- row_inside<Q, 1> for the seven other periods, decided before any of them does its book-keeping: they only
