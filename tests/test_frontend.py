@@ -101,6 +101,8 @@ def side_files():
         if fn.endswith(".dot"):
             name, rest = fn.split(".", 1)
             out.append((name, rest))
+    # the goldens are part of the repository (.gitignore excepts them): a checkout without them must not pass empty
+    assert len(out) >= 7, "tests/golden/side/*.dot missing: %d found" % len(out)
     return out
 
 
