@@ -50,6 +50,9 @@
 #ifndef WALK_PROBE_PERIODS
 #define WALK_PROBE_PERIODS 5u
 #endif
+#ifndef WALK_TAIL
+#define WALK_TAIL 8u         /* a probe with period p starts only where 4 p + WALK_TAIL positions of the region are left */
+#endif
 
 namespace mfa_walk {
 
@@ -174,15 +177,14 @@ WALK_DEV void w_rt_entry(const WIn& in, uint32_t e, uint32_t& lo, uint32_t& hi, 
 }
 // the region with the smallest period that contains scan index i and leaves room for a probe; next = the nearest region start behind i
 template <bool REV>
-WALK_DEV bool w_rt_find(const WIn& in, uint32_t i, uint32_t mult, uint32_t& lo, uint32_t& hi, uint32_t& q, uint32_t& next) {
+WALK_DEV bool w_rt_find(const WIn& in, uint32_t i, uint32_t& lo, uint32_t& hi, uint32_t& q, uint32_t& next) {
     bool found = false;
     next = ~0u; lo = hi = q = 0u;
     for (uint32_t e = 0; e < in.rt_cnt; e++) {
         uint32_t l, h, qq;
         w_rt_entry<REV>(in, e, l, h, qq);
         if (l <= i && i < h) {
-            const uint32_t m = qq * mult > 16u ? 1u : mult;
-            if (h - i >= 4u * qq * m + 24u && (!found || qq < q)) { found = true; lo = l; hi = h; q = qq; }
+            if (h - i >= 4u * qq + WALK_TAIL && (!found || qq < q)) { found = true; lo = l; hi = h; q = qq; }
         } else if (l > i && l < next) next = l;
     }
     return found;
@@ -740,9 +742,10 @@ WALK_DEV void frame_state(const Ent<U, K>& E, U pos, uint32_t cm, uint32_t com, 
 template <class U, int K, bool REV, class TP>
 WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uint32_t cur, uint32_t n_cur, uint32_t& n_next,
                         const U i, const U len, const uint32_t ch, const bool final_pass, const bool active, const bool dual_lane,
-                        bool& accept, bool& fits, tb_t& TB) {
+                        bool& accept, bool& fits, tb_t& TB, uint32_t& shape) {
     StepCtx<U, K> cx{st, cur ^ 1u, 0u, dual_lane, fits, TB, {}};
     cx.keys.seen = 0ull;
+    uint32_t sh = 0u;                                                // the vnodes of the list read, in list order, folded into one word (ShapeHist)
 #pragma unroll
     for (uint32_t k = 0; k < KeyCache<U>::N; k++) cx.keys.id[k] = 0xffffffffu;
     const uint32_t cls = (active && !final_pass) ? (T[au.cmap() + ((ch & 0xffu) >> 2)] >> (8u * (ch & 3u))) & 0xffu : 0u;
@@ -766,6 +769,10 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
         const bool wait = live && !final_pass && !here;
         const uint32_t vi = have ? T[au.vinfo() + E.vid] : 0u;
         const uint32_t node = E.vid >> au.vbits();
+        if (have) {                                                  // (a state the scan has passed counts as far ahead: it only holds its node)
+            const uint32_t ahead = val(pos) - val(i);
+            sh = ((sh << 7) | (sh >> 25)) ^ (E.vid * 4u + (ahead < 3u ? ahead : 3u) + 0x9e37u);
+        }
         // an epsilon edge: the state reaches `finish`, which keeps it iff pos == len (mfa.cpp:138-147); accepting is sticky
         if ((vi & VI_EPS) && live && !accept && eq(pos, len, cx.TB)) accept = true;
         {   // a waiting state goes back into the set as it is (mfa.cpp:195-197): older than everything created in this step
@@ -823,7 +830,7 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
             }
         }
     }
-    n_next = cx.n_next; fits = cx.fits; TB = cx.TB;
+    n_next = cx.n_next; fits = cx.fits; TB = cx.TB; shape = sh;
 }
 
 // ---- the list one period ago (SB) and its movement (SA) ----------------------------------------------------------------------------------
@@ -965,21 +972,53 @@ WALK_DEV unsigned long long wv_clock() { return __builtin_readcyclecounter(); }
 
 // Feeder::take(want, sid): hands the next string index to every lane that wants one; returns false when the batch is exhausted
 // The probe's small counters in ONE register (they are all alive across the step, where the kernel's register peak is: seven registers
-// less there): phase 0..3 | pk, pp <= 16 | mult 1..8 | fails < 8 | log2 of the back-off (8 .. 4096) | plain periods of the probe (saturating)
+// less there): phase 0..3 | pk, pp <= 16 | pmin (periods below it have failed in this region) | fails < 8 | log2 of the back-off (8 .. 4096)
+// | plain periods of the probe (saturating) | chain (1: the lane has just jumped and tries the same movement again after one period)
 struct ProbeCtl {
     uint32_t w;
     WALK_DEV uint32_t get(uint32_t sh, uint32_t bits) const { return (w >> sh) & ((1u << bits) - 1u); }
     WALK_DEV void put(uint32_t sh, uint32_t bits, uint32_t v) { w = (w & ~(((1u << bits) - 1u) << sh)) | ((v & ((1u << bits) - 1u)) << sh); }
-    WALK_DEV void reset() { w = 0u; set_pp(1u); set_mult(1u); backoff_reset(); }
+    WALK_DEV void reset() { w = 0u; set_pp(1u); backoff_reset(); }
     WALK_DEV uint32_t phase() const { return get(0, 2); }   WALK_DEV void set_phase(uint32_t v) { put(0, 2, v); }
     WALK_DEV uint32_t pk() const { return get(2, 5); }      WALK_DEV void set_pk(uint32_t v) { put(2, 5, v); }      WALK_DEV void inc_pk() { set_pk(pk() + 1u); }
     WALK_DEV uint32_t pp() const { return get(7, 5); }      WALK_DEV void set_pp(uint32_t v) { put(7, 5, v); }
-    WALK_DEV uint32_t mult() const { return get(12, 4); }   WALK_DEV void set_mult(uint32_t v) { put(12, 4, v); }
-    WALK_DEV uint32_t fails() const { return get(16, 4); }  WALK_DEV void set_fails(uint32_t v) { put(16, 4, v); }  WALK_DEV void inc_fails() { set_fails(fails() + 1u); }
+    WALK_DEV uint32_t pmin() const { return get(12, 5); }   WALK_DEV void set_pmin(uint32_t v) { put(12, 5, v); }
+    WALK_DEV uint32_t fails() const { return get(17, 3); }  WALK_DEV void set_fails(uint32_t v) { put(17, 3, v); }  WALK_DEV void inc_fails() { set_fails(fails() + 1u); }
     WALK_DEV uint32_t backoff() const { return 1u << get(20, 4); }
     WALK_DEV void backoff_reset() { put(20, 4, 3u); }
     WALK_DEV void backoff_double() { const uint32_t l = get(20, 4); put(20, 4, l < 12u ? l + 1u : l); }
-    WALK_DEV uint32_t nper() const { return get(24, 8); }   WALK_DEV void set_nper(uint32_t v) { put(24, 8, v); }   WALK_DEV void inc_nper() { const uint32_t n = nper(); set_nper(n < 255u ? n + 1u : n); }
+    WALK_DEV uint32_t nper() const { return get(24, 4); }   WALK_DEV void set_nper(uint32_t v) { put(24, 4, v); }   WALK_DEV void inc_nper() { const uint32_t n = nper(); set_nper(n < 15u ? n + 1u : n); }
+    WALK_DEV uint32_t chain() const { return get(28, 1); }  WALK_DEV void set_chain(uint32_t v) { put(28, 1, v); }
+    WALK_DEV uint32_t nochain() const { return get(29, 1); } WALK_DEV void set_nochain(uint32_t v) { put(29, 1, v); }      // the last attempt of that kind failed: not in this region again
+};
+
+// The shapes of the lists of a lane's last 12 steps (a list's vnodes and how far ahead of the scan each entry is -- 0, 1, 2, more --, in list
+// order, folded to 5 bits by the step): field k = the list k steps before the one the next step will read; bits 60..63 = how many fields are
+// valid.  A probe with period p starts only when the shape repeated with lag p: no probe in the middle of a transient, and the period of the
+// LIST (a multiple of the input's) is read off instead of being guessed.  A jump skips whole periods of a list whose shape has that period:
+// the history stays valid across it.
+constexpr uint32_t HIST_MAX_P = 10u, HIST_N = 12u;
+struct ShapeHist {
+    uint64_t h;
+    WALK_DEV void reset() { h = 0ull; }
+    WALK_DEV void push(uint32_t shape) {
+        uint32_t c = (uint32_t)(h >> 60);
+        c = c < HIST_N ? c + 1u : HIST_N;
+        const uint32_t x = (shape * 0x9e3779b1u) >> 27;
+        h = ((uint64_t)c << 60) | ((h << 5) & 0x0fffffffffffffe0ull) | x;
+    }
+    WALK_DEV bool lag(uint32_t p) const {                    // did the shapes of the last two steps occur p steps earlier?
+        const uint32_t c = (uint32_t)(h >> 60);
+        if (p + 2u > c) return false;
+        return ((h ^ (h >> (5u * p))) & 1023ull) == 0ull;
+    }
+    // the smallest multiple p of q with pmin <= p <= HIST_MAX_P that the history supports; 0: none (yet)
+    WALK_DEV uint32_t period(uint32_t q, uint32_t pmin) const {
+        uint32_t found = 0u;
+        for (uint32_t p = q; p <= HIST_MAX_P; p += q)
+            if (found == 0u && p >= pmin && lag(p)) found = p;
+        return found;
+    }
 };
 
 template <int K, bool REV, class Feeder, class TP>
@@ -990,11 +1029,12 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
     in.w0 = in.w1 = in.w2 = in.w3 = 0;
     bool active = false, exhausted = false, accept = false;
     uint32_t i = 0, len = 0;      // (the string's number is in.sid: a launch holds fewer than 2^32 strings)
-    // probes: P.phase() 0 idle, 1 = plain periods after saving the list, 2 = the dual period
-    // probes: phase 0 idle, 1 = plain periods after saving the list, 2 = the dual period
+    // probes: P.phase() 0 idle, 1 = plain periods after saving the list, 2 = the dual period, 3 = the dual period is over and looked sound
     uint32_t probe_at = 0;
     ProbeCtl P;
     P.reset();
+    ShapeHist hist;
+    hist.reset();
     tb_t TBacc = tb_init();
     bool fits = true, stable = false, patient = false;
     uint32_t cur = 0, n_cur = 0, sb_n = 0, warm = 0;
@@ -1028,7 +1068,8 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                             for (uint32_t k = 1; k < b.n_seg; k++)
                                 if (sid >= b.seg_first[k]) seg = k;
                             aut_load(au, T, b.n_seg ? b.seg_table[seg] : 0u);
-                            i = 0; accept = false; active = true; P.set_phase(0); probe_at = 0; P.backoff_reset(); P.set_pp(1); P.set_fails(0); P.set_mult(1); P.set_nper(0);
+                            i = 0; accept = false; active = true; probe_at = 0;
+                            P.reset(); hist.reset();
                             stable = false; patient = false;
                             n_cur = 1;                                // the list: (pos 0, start, no cells)  mfa.cpp:217-219
                             Ent<uint32_t, K> e0;
@@ -1049,37 +1090,58 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
         uint32_t ch = 0x100u;
         if (active && !final_pass) ch = w_stream_byte<REV>(in, i);
         WALK_LAP(t_byte);
-        // ---- does this lane sit at the start of a stretch that repeats?  (probes run in epochs: all lanes that probe do it together)
+        // ---- a lane that has just jumped tries the same movement again one period later: a jump ends where a comparison is about to change its
+        // outcome, and what follows is often the same movement of another state (a cell opened later takes over): the list is saved, gets the
+        // movement of the last jump as its directions and goes through a dual period at once -- which proves the movement or refutes it
+        {
+            const bool again = b.accel && active && !final_pass && P.phase() == 0u && P.chain() != 0u && i == probe_at;
+            const bool room = again && in.per_q != 0u && in.per_lo <= i && in.per_hi >= i + 1u + 2u * P.pp() && n_cur == sb_n;
+            if (again) P.set_chain(0u);
+            if (__any(room)) {
+                image_save<K>(st, cur, room, n_cur);
+                image_dirs<K>(st, cur, room, n_cur);
+            }
+            if (room) { P.set_phase(2u); P.set_pk(0u); P.set_nper(15u); TBacc = tb_init(); fits = true; if (stats) stats->probes++; }
+        }
+        // ---- does this lane sit in a stretch that repeats, with a list whose shape has repeated?  (probes run in epochs: all lanes that measure do
+        // it together, with the same period)
         uint32_t q = 0u;
-        const bool ep_busy = __any(P.phase() != 0u);
+        const bool ep_busy = __any(P.phase() == 1u);
         if (b.accel && active && !final_pass && P.phase() == 0u && i >= probe_at && !ep_busy) {
             if (in.per_q != 0u && in.per_lo <= i && i < in.per_hi) q = in.per_q;      // still inside the region found last
             else if (in.regions != nullptr) {
                 uint32_t rl, rh, rq, rn;
-                if (w_rt_find<REV>(in, i, P.mult(), rl, rh, rq, rn)) {
+                if (w_rt_find<REV>(in, i, rl, rh, rq, rn)) {
                     if (in.per_q != 0u) { in.prev_lo = in.per_lo; in.prev_hi = in.per_hi; in.prev_q = in.per_q; }
                     in.per_lo = rl; in.per_hi = rh; in.per_q = rq; q = rq;
+                    P.set_pmin(0u); P.set_nochain(0u); patient = false;
                 } else probe_at = rn;                                        // look again where the next region starts (never, if there is none)
             } else probe_at = ~0u;                                           // no table: every step is executed
         }
         if (q == 1u) { in.run_lo = i; in.run_hi = in.per_hi; in.run_ch = ch; }
-        if (q != 0u && q * P.mult() > 16u) P.set_mult(1u);
-        const unsigned long long cand = __ballot(q != 0u && in.per_hi - i >= 4u * q * P.mult() + 24u);
-        const uint32_t ep_pp = cand ? __shfl(q * P.mult(), __builtin_ctzll(cand)) : 0u;      // the first candidate's period leads the epoch
+        uint32_t want_p = 0u;
+        if (q != 0u) {
+            if (in.per_hi - i < 4u * q + WALK_TAIL) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // too short to be worth a probe
+            else {
+                want_p = hist.period(q, P.pmin());
+                if (want_p != 0u && in.per_hi - i < 4u * want_p + WALK_TAIL) want_p = 0u;
+            }
+        }
+        const unsigned long long cand = __ballot(want_p != 0u);
+        const uint32_t ep_pp = cand ? __shfl(want_p, __builtin_ctzll(cand)) : 0u;      // the first candidate's period leads the epoch
         {
             bool begin = false;
-            if (q != 0u) {
-                P.set_pp(ep_pp);
-                if (ep_pp != 0u && ep_pp % q == 0u && in.per_hi - i >= 4u * P.pp() + 24u) {
-                    begin = true; P.set_phase(1u); P.set_pk(0u); P.set_nper(0u); stable = false; sb_n = n_cur;
+            if (want_p != 0u || (q != 0u && ep_pp != 0u)) {
+                // (a lane whose own choice differs joins if the epoch's period suits its list as well)
+                if (ep_pp % q == 0u && ep_pp >= P.pmin() && (want_p == ep_pp || hist.lag(ep_pp)) && in.per_hi - i >= 4u * ep_pp + WALK_TAIL) {
+                    begin = true; P.set_pp(ep_pp); P.set_phase(1u); P.set_pk(0u); P.set_nper(0u); stable = false; sb_n = n_cur;
                     if (stats) stats->probes++;
-                } else if (in.per_hi - i < 4u * q * P.mult() + 24u) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;      // too short to be worth a probe
-                else probe_at = i + 1u;                                                                                  // does not fit this epoch's period
+                }
             }
             if (__any(begin)) image_save<K>(st, cur, begin, n_cur);
         }
         WALK_LAP(t_look);
-        uint32_t n_next = 0;
+        uint32_t n_next = 0, shape = 0;
         tb_t TB = tb_init();
         const bool p2 = P.phase() == 2u;
         const bool accept_before = accept, fits_before = fits;
@@ -1093,42 +1155,45 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                 in.dual_p = p2 ? P.pp() : 0u;
                 (void)lt(di, Dual{p2 ? in.per_hi : i + 1u, 0}, TB);     // the byte at this step of the period repeats while i is inside the region
                 (void)eq(di, dlen, TB);
-                walk_step<Dual, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB);
+                walk_step<Dual, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, di, dlen, ch, final_pass, active, p2, accept, fits, TB, shape);
                 in.dual_p = 0u;
                 WALK_LAP(t_dual);
             } else {
                 bool f2 = true;
-                walk_step<uint32_t, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB);
+                walk_step<uint32_t, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB, shape);
                 WALK_LAP(t_plain);
             }
             if (!__any(active && in.rq != 0u)) break;
             answer_requests<REV>(st, in, active);
         }
         cur ^= 1u;
-        if (active) n_cur = n_next;
+        if (active) { n_cur = n_next; hist.push(shape); }
         const bool any_next = n_next != 0u;
         if (stats && active && n_cur > st.C) stats->spills++;
 #ifdef MFA_HOST_EMUL
         if (stats && active) stats->hist[n_cur < 79u ? n_cur : 79u]++;
 #endif
         uint32_t skip = 0;
+        const bool chained = p2 && P.nper() == 15u;                  // this dual period repeats the last jump's movement (no plain periods before it)
+        // a probe that did not lead to a jump: the first failure after an optimistic start (one plain period) makes the lane patient (two equal
+        // movements before the next dual period); after that the period is given up for this region (the list may move with a multiple of it)
+        auto probe_failed = [&]() {
+            P.inc_fails();
+            if (!patient) patient = true;
+            else P.set_pmin(P.pp() + 1u);
+            if (P.fails() >= 6u || P.pmin() > HIST_MAX_P) { P.set_fails(0u); P.set_pmin(0u); P.backoff_double(); }
+        };
         if (p2) {
             tb_min(TBacc, TB.a, TB.b);
             P.inc_pk();
-            bool ended = false;
             if (P.pk() == P.pp()) {
                 const int64_t periods = tb_steps(TBacc);
-                bool same = !accept && any_next && periods > 1 && fits;
-                ended = true;
-                // (the comparison below is wave-level code: done after this block)
-                if (!same) ended = true;
-                P.set_phase(same ? 3u : 0u);                              // 3: the comparison with the image decides
+                const bool same = !accept && any_next && periods > 1 && fits;
+                P.set_phase(same ? 3u : 0u);                              // 3: the comparison with the image decides (wave-level code: below)
             } else if (tb_is_one(TBacc) || accept || !any_next) {
-                P.set_phase(0u); P.inc_fails();                                 // cannot succeed any more: stop the probe here
-                if (P.nper() == 1u && !patient && P.pp() > 2u) patient = true; else P.set_mult(P.mult() % 8u + 1u);
-                if (P.fails() >= 8u) { P.set_fails(0u); P.backoff_double(); }
+                P.set_phase(0u);                                          // cannot succeed any more: stop the probe here
+                if (!chained) probe_failed(); else P.set_nochain(1u);
             }
-            (void)ended;
         }
         if (__any(P.phase() == 3u)) {
             const bool same = image_same<K>(st, cur, P.phase() == 3u, n_cur, sb_n);
@@ -1141,22 +1206,18 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
             }
         }
         if (p2 && P.pk() == P.pp() && P.phase() == 0u) {
-            if (skip) { P.backoff_reset(); P.set_fails(0u); if (stats) { stats->hits++; stats->skipped += (unsigned long long)skip * P.pp(); } }
-            else {
-                // a failed dual period: after an optimistic start (one plain period) the next probe of this string waits for two equal
-                // movements; otherwise the list may repeat with a multiple of the period
-                P.inc_fails();
-                if (P.nper() == 1u && !patient && P.pp() > 2u) patient = true; else P.set_mult(P.mult() % 8u + 1u);
-                if (P.fails() >= 8u) { P.set_fails(0u); P.backoff_double(); }
-            }
+            if (skip) { P.backoff_reset(); P.set_fails(0u); patient = false; if (stats) { stats->hits++; stats->skipped += (unsigned long long)skip * P.pp(); } }
+            else if (!chained) probe_failed();
+            else P.set_nochain(1u);
         }
         if (__any(skip != 0u)) image_advance<K>(st, cur, skip != 0u, n_cur, skip);
-        if (skip) { i += skip * P.pp(); w_drop_window(in); probe_at = i + 1u + P.pp(); }
-        else if (p2 && P.phase() == 0u) probe_at = i + (P.fails() ? 1u : P.backoff());
+        if (skip) { i += skip * P.pp(); w_drop_window(in); probe_at = i + 1u + P.pp(); P.set_chain(P.nochain() ^ 1u); sb_n = n_cur; }      // (i is incremented below: the next period, then the same movement again)
+        else if (p2 && P.phase() == 0u) probe_at = i + ((chained || P.fails()) ? 1u : P.backoff());
         if (P.phase() == 1u) P.inc_pk();
         // plain periods of a probe: after each one the movement of the list over the period is compared with the previous period's; a
-        // lane is ready for the dual period once two consecutive movements agree.  All lanes of an epoch reach their period
-        // boundaries in the same iteration and go on together.
+        // lane is ready for the dual period after the first period if the list kept its nodes (optimistic: the dual period itself proves or
+        // refutes the movement), a patient lane once two consecutive movements agree.  All lanes of an epoch reach their period boundaries in
+        // the same iteration and go on together.
         {
             const bool at_end = P.phase() == 1u && P.pk() == P.pp();
             if (__any(at_end)) {
@@ -1164,7 +1225,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                 image_measure<K>(st, cur, at_end, n_cur, sb_n, moved, wide, vac);
                 if (at_end) {
                     const bool eqd = P.nper() != 0u && !moved;
-                    const bool occ = P.nper() == 0u && !patient && P.pp() > 2u && !vac;      // first period: the same nodes before and after it
+                    const bool occ = P.nper() == 0u && !patient && !vac;      // first period: the same nodes before and after it
                     fits = !wide;
                     sb_n = n_cur;
                     P.inc_nper(); P.set_pk(0u); stable = (eqd || occ) && fits;
@@ -1174,17 +1235,16 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
         {
             const bool at_b = P.phase() == 1u && P.pk() == 0u && P.nper() != 0u;
             if (__any(at_b)) {
-                const bool room = in.per_hi >= i + 1u + 2u * P.pp();      // the dual period and at least one more to skip
+                const bool room = in.per_hi >= i + 2u + 2u * P.pp();      // the dual period and at least one more to skip
                 if (!__any(at_b && !stable && room && P.nper() < (P.pp() > 2u ? WALK_PROBE_PERIODS : 3u))) {
                     const bool go = at_b && stable && room;
                     if (__any(go)) image_dirs<K>(st, cur, go, n_cur);
-                    if (go) { P.set_phase(2u); TBacc = tb_init(); P.set_pk(0u); }
+                    if (go) { P.set_phase(2u); TBacc = tb_init(); P.set_pk(0u); if (P.nper() == 15u) P.set_nper(14u); }
                     else if (at_b) {
                         P.set_phase(0u);
                         if (!room) probe_at = in.per_hi > i + 1u ? in.per_hi : i + 1u;
-                        else {                                        // never settled: maybe the list repeats with a multiple of the period
-                            P.inc_fails(); P.set_mult(P.mult() % 8u + 1u);
-                            if (P.fails() >= 8u) { P.set_fails(0u); P.backoff_double(); }
+                        else {                                        // never settled
+                            probe_failed();
                             probe_at = i + 1u + (P.fails() ? 0u : P.backoff());
                         }
                     }
@@ -1197,7 +1257,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
             if (stats) stats->steps++;
             if (done) {
                 b.results[in.sid] = (warm == 0x9e3779b9u && len == 0xffffffffu) ? 3 : (accept ? 1 : 0);      // (warm keeps the touches alive)
-                active = false; P.set_phase(0u); n_cur = 0u;
+                active = false; P.set_phase(0u); P.set_chain(0u); n_cur = 0u;
                 if (stats) stats->strings++;
             }
         }
