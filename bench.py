@@ -33,7 +33,7 @@ KERNEL_NAMES = {1: "walk_kernel (table-driven)", 2: "mfa_jit_kernel (generated f
 PARITY_FRACTION = 0.01         # seeded sample of every example's shard (no length cap) re-checked on the CPU after the timed region
 BASELINE_N = 48                # first strings of every example kept on the host for the reference-build baseline
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")      # PMC counters of one headline step (tools/profile_round.sh), stamped with the kernel sources' hash
 
 
 def spawn_ranks(args):
@@ -86,6 +86,28 @@ def spawn_ranks(args):
                 p.wait()
             break
     return rc
+
+
+def host_cores(limit=32):
+    """this process's CPU share (the GPU box gives one GPU's share of the host, not all of its cores), `limit` at most"""
+    return max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), limit))
+
+
+def hbm_preflight(n_per, min_len, max_len, world, rank, device_index):
+    """What a rank's shard needs in HBM against what its device has free, printed before anything is allocated (stderr, every rank):
+    the batch, its offsets and results, the region table (128 B per string), and the generator's temporaries (8 bytes-sized int64
+    vectors over a 128 MiB chunk).  Returns (need, free) in bytes."""
+    import math
+    import torch
+    mean_len = (max_len - min_len) / max(math.log(max_len / max(min_len, 1)), 1e-9) if max_len > min_len else max_len      # log-uniform pump sizes
+    strings = 10 * n_per
+    need = int(strings * (mean_len + 8 + 1 + 128) + 9 * (1 << 27) * 8)
+    free, total = torch.cuda.mem_get_info(device_index)
+    sys.stderr.write("bench.py: rank %d/%d device %d: shard needs about %.1f GB of HBM (batch %.1f GB + tables and temporaries), %.1f GB free of %.1f GB\n"
+                     % (rank, world, device_index, need / 1e9, strings * mean_len / 1e9, free / 1e9, total / 1e9))
+    if need > free:
+        sys.stderr.write("bench.py: rank %d: NOT ENOUGH free HBM for this shard\n" % rank)
+    return need, free
 
 
 def load_blob(name):
@@ -161,7 +183,7 @@ def cpu_baseline(corpus, shards, gpu_results, budget_strings=8, cap=32768):
                 jobs.append((blob_path, sample))
             # the restatement on every host core: the parity sample dealt round-robin to one process per core
             # this process's CPU share (the GPU box gives one GPU's share of the host, not all of its cores)
-            cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16))
+            cores = host_cores()
             from concurrent.futures import ThreadPoolExecutor
             work = []
             for blob_path, sample in jobs:
@@ -209,7 +231,7 @@ def parity_sample(jobs, cores=None):
     cli = os.path.join(ROOT, "oracle", "oracle_cli")
     if not os.path.exists(cli):
         return None
-    cores = cores or max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 32))
+    cores = cores or host_cores()
     from concurrent.futures import ThreadPoolExecutor
     t0 = time.perf_counter()
     n_str = n_bytes = max_len = mism = 0
@@ -342,6 +364,61 @@ def secondary_config3(device, capi, n_strings=1 << 20, length=65536):
             "frac_of_hbm_peak_on_touched_bytes": nbytes / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "region_pass_GB/s": nbytes / (tr * 1e-3) / 1e9 if tr > 0 else None,
             "results_as_expected": ok, "parity_sample": par}
+
+
+def secondary_config3_loguniform(device, capi, corpus, n_strings=1 << 20, lo=1024, hi=65536):
+    """BASELINE.json configs[2], the SECONDARY variant of SURVEY section 8d (config 3): example 1, 1M strings, the same 4-way mix by
+    j mod 4 (a^(L-1) b, a^L, a^L with one byte at a seeded position set to b, i.i.d. {a: 0.99, b: 0.01}) with lengths log-uniform in
+    [1 KiB, 64 KiB], seed 0x5EED0003; generated on the device.  Its own parity sample (0.1 % of the strings, full length)."""
+    import numpy as np
+    import torch
+    blob = load_blob("ex1_plain")
+    img = capi.Image(blob)
+    lens = corpus.pump_sizes(n_strings, 0x5EED0003, lo, hi)
+    off_h = np.zeros(n_strings + 1, dtype=np.int64)
+    np.cumsum(lens, out=off_h[1:])
+    total = int(off_h[-1])
+    g = torch.Generator(device=device); g.manual_seed(0x5EED0003)
+    flat = torch.empty(total + 64, dtype=torch.uint8, device=device)
+    flat.fill_(ord("a"))
+    flat[-64:] = 0
+    off = torch.from_numpy(off_h).to(device)
+    j = torch.arange(n_strings, device=device)
+    flat[off[1:][j % 4 == 0] - 1] = ord("b")                                           # kind 0: a^(L-1) b
+    k2 = j[j % 4 == 2]
+    pos = (torch.rand(k2.numel(), generator=g, device=device, dtype=torch.float64) * torch.from_numpy(lens).to(device)[k2]).long()
+    flat[off[:-1][k2] + pos] = ord("b")                                                # kind 2: one b somewhere
+    chunk = 1 << 27                                                                    # kind 3: noise, over the strings' own bytes only
+    for a in range(0, total, chunk):
+        b = min(total, a + chunk)
+        p = torch.arange(a, b, device=device)
+        sid = torch.searchsorted(off, p, right=True) - 1
+        m = ((sid & 3) == 3) & (torch.rand(b - a, generator=g, device=device) < 0.01)
+        flat[a:b].masked_fill_(m, ord("b"))
+        del p, sid, m
+    res = torch.empty(n_strings, dtype=torch.uint8, device=device)
+    t, tr = _timed(img, flat, off, res, device, reps=2)
+    mx = capi.Mixed([img])
+    res_m = torch.empty(n_strings, dtype=torch.uint8, device=device)
+    spans = []
+    for _ in range(3):
+        mx.match_tensors(flat, off, [0, n_strings], res_m); torch.cuda.synchronize()
+        spans.append(mx.last_ms(device.index or 0))
+    span = float(np.mean([x[1] for x in spans[1:]]))
+    same = bool(torch.equal(res, res_m))
+    mx.close()
+    ok = bool(res[1::4].all().item()) and not bool(res[0::4].any().item()) and not bool(res[2::4].any().item()) and not bool(res[3::4].any().item())
+    rng = np.random.Generator(np.random.Philox(0x5EED0015))
+    idx = np.sort(rng.choice(n_strings, size=max(8, n_strings // 1024), replace=False))
+    strings = [bytes(flat[int(off_h[k]):int(off_h[k + 1])].cpu().numpy().tobytes()) for k in idx]
+    par = parity_sample([(blob, strings, res[torch.from_numpy(idx).to(device)].cpu().numpy())])
+    return {"workload": "configs[2], secondary variant: ({a*}:1&1)*, %d strings, lengths log-uniform [%d, %d] (%.1f GB), 4-way attack mix" % (n_strings, lo, hi, total / 1e9),
+            "kernel": "region_scan_kernel + " + KERNEL_NAMES.get(img.info()["last_kernel"], "?"), "region_ms": tr, "walk_ms": t,
+            "GB/s": total / ((t + tr) * 1e-3) / 1e9, "touched_bytes": total,
+            "frac_of_hbm_peak_on_touched_bytes": total / ((t + tr) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "mixed_call": {"span_ms": span, "GB/s": total / (span * 1e-3) / 1e9, "frac_of_hbm_peak_on_touched_bytes": total / (span * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "results_equal": same},
+            "closed_form_check": ok, "accepted": int(res.sum().item()), "parity_sample": par}
 
 
 def secondary_64k_all_examples(device, capi, corpus, n_strings=16384):
@@ -535,13 +612,25 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # MFA_BENCH_FORCE_DIST=1: a single rank still goes through torch.distributed (backend nccl = RCCL: communicator on the device,
+    # all_gather / gather / all_reduce / barrier on device tensors) -- what a 1-GPU box can execute of the N > 1 path
+    force_dist = os.environ.get("MFA_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"] = "127.0.0.1"
+        if "MASTER_PORT" not in os.environ:
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if world > 1 or force_dist:
+        hbm_preflight(args.strings_per_example, args.min_len, args.max_len, world, rank, local)
     comm_dev = torch.device("cpu") if rehearse else device
 
     # ---- this rank's shard: ONE mixed batch, resident in HBM ------------------------------------------
@@ -615,7 +704,7 @@ def main():
 
     def step(record):
         """one pass of the hot path: one library call for the whole mixed batch, then the result bitmap goes to rank 0"""
-        mixed.match_tensors(bytes_all, off_all, seg, results)
+        mixed.match_tensors(bytes_all, off_all, seg, results, total_bytes=total_bytes)
         full = sharding.gather_results(results, counts, dist, rank, world, comm_device=comm_dev) if dist else None
         if dist is None:
             full = sharding.pack_bitmap(results)                 # the bitmap a gather would send
@@ -672,21 +761,28 @@ def main():
         for ex, sh in shards.items():
             a = sh["first"]
             per_ex[str(ex)] = {"bytes": sh["nbytes"], "strings": sh["n"], "accepted": int((results[a:a + sh["n"]] == 1).sum().item())}
-        traffic = None
+        # HBM traffic of a step: PMC counters collected in a separate run (FETCH_SIZE / WRITE_SIZE passes).  Quoted only for the workload
+        # they were collected on AND while the kernel sources are the ones they were collected with; otherwise null, with the reason
+        traffic, traffic_note = None, None
         try:
+            from mfa_amd import srchash
             with open(TRAFFIC_FILE) as f:
                 tj = json.load(f)
             wl = tj["workload"]
-            if (wl["strings_per_example"], wl["min_len"], wl["max_len"]) == (n_per, args.min_len, args.max_len):
+            if (wl["strings_per_example"], wl["min_len"], wl["max_len"]) != (n_per, args.min_len, args.max_len):
+                traffic_note = "counters in %s are for another workload" % os.path.basename(TRAFFIC_FILE)
+            elif tj.get("csrc_sha16") != srchash.kernel_source_hash():
+                traffic_note = "counters in %s were collected with other kernel sources (%s, now %s)" % (
+                    os.path.basename(TRAFFIC_FILE), tj.get("csrc_sha16"), srchash.kernel_source_hash())
+            else:
                 traffic = tj["hbm_bytes_per_step"]
-        except (OSError, KeyError, ValueError):
-            pass
-        # the library's rule (walk_launch.hip): MFA_MIXED_CUTS, or one group per 1.3 GB (2 GB with generated kernels) of the batch, 8 (5) at most
-        if os.environ.get("MFA_MIXED_CUTS") is not None:
-            n_groups = len([c for c in os.environ["MFA_MIXED_CUTS"].split(",") if c]) + 1
-        else:
-            jit_engine = os.environ.get("MFA_WALK", "") == "jit"
-            n_groups = 1 if total_strings < 65536 else int(min(5 if jit_engine else 8, max(1, (total_bytes / (2.0e9 if jit_engine else 1.3e9) + 0.5) // 1)))
+                traffic_note = "%s: separate --pmc passes over one step, FETCH_SIZE doubled (gfx950), kernel sources %s" % (os.path.basename(TRAFFIC_FILE), tj["csrc_sha16"])
+        except (OSError, KeyError, ValueError) as e:
+            traffic_note = "no counters: %s" % e
+        # what a step launches, from the library itself (mfa_mixed_last_launches): with the gate ONE region launch over the whole batch and
+        # the walks of a group released by its counter; otherwise one region launch per group of strings
+        launches = mixed.last_launches(local)
+        n_groups, n_region = launches["groups"], launches["region_launches"]
         out = {
             "metric": "input GB/s (chars matched/sec) on 10-example attack corpus",
             "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -703,14 +799,16 @@ def main():
                        "bytes_per_gpu": total_bytes, "parallelism": "dp%d" % world,
                        "exchange": "gather of the result bitmap to rank 0" + (" (%s)" % dist.get_backend() if dist else " (single rank: none)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "region_scan_kernel (%d launches over groups of strings, on one stream) + %s; duration = first region launch to end of the last walk" % (
-                             n_groups, engine),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": "region_scan_kernel (%s) + %s in %d launches; duration = first region launch to end of the last walk" % (
+                             "ONE launch over the batch, the walks of each of %d groups of strings released by a counter the kernel raises" % n_groups if launches["gated"]
+                             else "%d launches over groups of strings, on one stream" % n_region, engine, launches["walk_launches"]),
+                         "launches_per_step": launches,
                          "algorithmic_bytes_per_step": alg, "kernel_seconds_per_step": kern_s,
                          "kernel_ms_by_step": [round(x, 3) for x in span_ms[::-1]],
                          # the kernel that reads the bytes: its own launches, back to back on their stream, timed with HIP events
-                         "region_scan_kernel": {"launches_per_step": n_groups, "ms_per_step": reg_total_ms,
-                                                "ms_per_launch": reg_total_ms / n_groups,
+                         "region_scan_kernel": {"launches_per_step": n_region, "ms_per_step": reg_total_ms,
+                                                "ms_per_launch": reg_total_ms / max(n_region, 1),
                                                 "achieved": total_bytes / (reg_total_ms * 1e-3) / 1e9, "frac": total_bytes / (reg_total_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                                 "note": "runs beside the walk kernels of earlier groups"}},
             "order": layout, "per_example": per_ex,
@@ -734,7 +832,8 @@ def main():
             mixed.close()
             del bytes_all, off_all
             torch.cuda.empty_cache()
-            sec = [secondary_dfa(device, capi), secondary_config3(device, capi), secondary_64k_all_examples(device, capi, corpus)]
+            sec = [secondary_dfa(device, capi), secondary_config3(device, capi), secondary_config3_loguniform(device, capi, corpus),
+                   secondary_64k_all_examples(device, capi, corpus)]
             sec += secondary_no_regions(device, capi, corpus)
             sec += secondary_config5(device, capi, corpus)
             out["secondary"] = sec

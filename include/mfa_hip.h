@@ -136,7 +136,13 @@ int  mfa_match_batch_regions(mfa_image_t* img, const uint8_t* d_bytes, const uin
  * (MFA_ERR_UNSUPPORTED otherwise).  One call runs the region pass over the batch in a few groups of
  * consecutive segments and walks each group -- all its automata in ONE launch, any lane any automaton --
  * as soon as its regions are known, on internal streams: the walk of a group runs beside the region
- * pass of the next.  `stream` sees the call as a single operation (it waits for the internal streams). */
+ * pass of the next: one region launch per group, the walks wait for the event behind it.  (MFA_MIXED_GATE=1, table-driven
+ * walk only: the region pass is ONE launch over the whole batch; it counts every finished string for its group, a
+ * one-wave kernel in front of a group's walk launches ends when the group is complete, and every word of a table row
+ * carries the call's stamp, so that a walk never takes a row that has not arrived yet -- or a stale copy of an earlier
+ * call's -- for this call's.  Measured: not faster; kept as an option.)  `stream` sees the call as a single operation: it waits for the internal streams before the call
+ * returns, ALSO when the call returns an error (whatever was started is ordered before the caller's next
+ * operation on `stream`). */
 typedef struct mfa_mixed mfa_mixed_t;
 int  mfa_mixed_create(mfa_image_t* const* images, uint32_t n_images, mfa_mixed_t** out);
 void mfa_mixed_destroy(mfa_mixed_t* mx);
@@ -144,9 +150,15 @@ void mfa_mixed_destroy(mfa_mixed_t* mx);
  * seg_first[s] .. seg_first[s+1]-1 are matched against images[s].  Device pointers as in mfa_match_batch.
  * Asynchronous on `stream` -- except that the first call with a string count this object has not met (n >= 65536) reads the
  * batch's size in bytes back (offsets[n] - offsets[0]) to choose the number of groups, and waits for `stream` to do so
- * (make such a call outside a stream capture). */
+ * (make such a call outside a stream capture, or use mfa_match_mixed_sized), and that with the generated kernels (MFA_WALK=jit)
+ * the first call on a device times the walks and synchronises on its own end.  A later batch with the same string count and
+ * other bytes is grouped like the first: a matter of speed only. */
 int  mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                      const uint64_t* seg_first, uint8_t* d_results, int device, void* stream);
+/* the same for a caller that knows the batch's size in bytes (total_bytes = offsets[n] - offsets[0], > 0): nothing is read back,
+ * the call never waits for `stream` */
+int  mfa_match_mixed_sized(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes,
+                           const uint64_t* seg_first, uint8_t* d_results, int device, void* stream);
 /* the same with HOST pointers (copy in, match, copy out, synchronise): for callers that hold std::strings */
 int  mfa_match_mixed_host(mfa_mixed_t* mx, const uint8_t* bytes, const uint64_t* offsets, uint64_t n,
                           const uint64_t* seg_first, uint8_t* results, int device);
@@ -156,6 +168,9 @@ int  mfa_mixed_last_ms(mfa_mixed_t* mx, int device, float* region_ms, float* spa
 /* the same for the call `back` calls ago (0 = the last one; the events of the last 32 calls are kept, so a sequence of calls can be
  * timed without synchronising between them) */
 int  mfa_mixed_timing(mfa_mixed_t* mx, int device, uint32_t back, float* region_ms, float* span_ms);
+/* what the last call on `device` launched (any pointer may be NULL): region launches (1 when the walks are released by counters),
+ * walk launches, groups of strings, and gated = 1 if the walks were released by counters, 0 if by events */
+int  mfa_mixed_last_launches(mfa_mixed_t* mx, int device, uint32_t* region_launches, uint32_t* walk_launches, uint32_t* groups, uint32_t* gated);
 
 /* Same with HOST pointers: copies the batch to the device, matches, copies the
  * results back, synchronises.  Convenience for callers that hold std::strings

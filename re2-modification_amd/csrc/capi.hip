@@ -34,9 +34,16 @@ int ctx_reserve(void** buf, size_t* have, size_t need) {
     if (need <= *have) return MFA_OK;
     if (*buf) HIP_TRY(hipFree(*buf));
     *buf = nullptr; *have = 0;
-    need += need / 4;                                         // head room: batches of similar size do not reallocate
-    HIP_TRY(hipMalloc(buf, need));
-    *have = need;
+    const size_t want = need + need / 4;                      // head room: batches of similar size do not reallocate
+    hipError_t e = hipMalloc(buf, want);
+    if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) {      // not with head room: exactly what is needed, or an honest "no memory"
+        (void)hipGetLastError();
+        e = hipMalloc(buf, need);
+        if (e == hipErrorOutOfMemory || e == hipErrorMemoryAllocation) { (void)hipGetLastError(); *buf = nullptr; set_last_hip_error((int)e); return MFA_ERR_NOMEM; }
+        if (e == hipSuccess) { *have = need; return MFA_OK; }
+    }
+    if (e != hipSuccess) { *buf = nullptr; set_last_hip_error((int)e); return MFA_ERR_HIP; }
+    *have = want;
     return MFA_OK;
 }
 

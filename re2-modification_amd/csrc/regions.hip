@@ -235,7 +235,13 @@ __device__ __forceinline__ Geo make_geo(uint64_t b, uint64_t e, uint64_t ymax) {
     g.endblk = g.len >= 8u ? (int32_t)((g.off0 + g.len - 8u) >> 4) : 0;
     g.nrows = (g.nblk + 63) >> 6;
     g.lastoff = g.nblk > 0 ? 16u * (uint32_t)(g.nblk - 1) : 0u;
-    g.ylim = ymax - g.a0 < 0xfffffff0ull ? (uint32_t)(ymax - g.a0) : 0xfffffff0u;
+    {   // min(ymax - a0, 0xfffffff0) without a 64-bit comparison (a vector instruction with its constant in two registers: see the kernel)
+        const uint64_t d = ymax - g.a0;
+        uint64_t top;
+        asm("s_lshr_b64 %0, %1, 32" : "=s"(top) : "s"(d) : "scc");
+        const uint32_t dl = (uint32_t)d;
+        g.ylim = top != 0ull ? 0xfffffff0u : (dl < 0xfffffff0u ? dl : 0xfffffff0u);
+    }
     return g;
 }
 
@@ -371,8 +377,17 @@ __device__ __forceinline__ void scan_row(Scan& sc, uint32_t lane, const Geo& g, 
     sc.vp = v <= 8u ? v : 0u;
 }
 
+// A table word written for a reader that may start BEFORE this kernel ends (GATE: the walks of a group are released by a counter, below):
+// an agent-scope store goes through to memory (`sc1`) instead of staying dirty in this XCD's L2, which another XCD does not see.
+// (written out: as an atomic store of the language it cost the kernel two registers; `tab` is wave-uniform, the word's index per lane)
+template <bool GATE> __device__ __forceinline__ void row_store(uint64_t* tab, uint32_t word, uint64_t v) {
+    if (GATE) asm volatile("global_store_dwordx2 %0, %1, %2 sc1" :: "v"(word * 8u), "v"(v), "s"(tab) : "memory");
+    else tab[word] = v;
+}
+
 // exact ends of the candidates, clean-up, table row
-__device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo& g, const uint8_t* bytes, uint64_t total16, uint64_t* tab) {
+struct RowOut { bool entry; uint32_t rank; uint64_t word, header; };      // what a lane contributes to its string's table row
+__device__ __forceinline__ RowOut finish_string(Scan& sc, uint32_t lane, const Geo& g, const uint8_t* bytes, uint64_t total16) {
     RegionState& st = sc.st;
     // ---- exact ends: lane c resolves candidate c against the real bytes
     const uint32_t ncand = st.ncand < 64u ? st.ncand : 64u;
@@ -458,9 +473,76 @@ __device__ __forceinline__ void finish_string(Scan& sc, uint32_t lane, const Geo
             if (kf < key || (kf == key && (uint32_t)f < lane)) rank++;
         }
     }
-    if (keep && rank < MFA_REGION_MAX) tab[1 + rank] = (uint64_t)lo | ((uint64_t)hi << 24) | ((uint64_t)q << 48);
-    if (lane == 0) tab[0] = (uint64_t)(total < MFA_REGION_MAX ? total : MFA_REGION_MAX) |
-                            ((total > MFA_REGION_MAX || st.ncand >= 64u) ? MFA_REGION_OVERFLOW : 0ull);
+    RowOut out;
+    out.header = (uint64_t)(total < MFA_REGION_MAX ? total : MFA_REGION_MAX) | ((total > MFA_REGION_MAX || st.ncand >= 64u) ? MFA_REGION_OVERFLOW : 0ull);
+    out.entry = keep && rank < MFA_REGION_MAX;
+    out.rank = rank;
+    out.word = (uint64_t)lo | ((uint64_t)hi << 24) | ((uint64_t)q << 48);
+    return out;
+}
+
+// the row goes out.  GATE: in ONE store instruction -- the entries from their lanes, the header from the first lane that holds no entry (at
+// most 15 do) -- that goes through to memory
+template <bool GATE> __device__ __forceinline__ void row_out(uint64_t* tab, uint32_t lane, const RowOut& r, uint64_t stamp) {
+    if (GATE) {
+        const uint32_t hl = (uint32_t)__builtin_ctzll(~__ballot(r.entry));
+        if (r.entry || lane == hl) row_store<true>(tab, r.entry ? 1u + r.rank : 0u, (r.entry ? r.word : r.header) | stamp);
+    } else {
+        if (r.entry) tab[1 + r.rank] = r.word;
+        if (lane == 0) tab[0] = r.header;
+    }
+}
+
+// GATE: the strings of a batch are cut into groups (mfa_match_mixed), ONE launch of this kernel scans the whole batch, and the walk
+// launches of a group are released as soon as the group's strings are done -- while the kernel is still running.  Three parts:
+//   * every word of a row carries the STAMP of the call that wrote it (bits 52..63: the call's number, 12 bits).  A reader takes a word
+//     for what it says only if the stamp is the one it expects: a row that has not arrived yet, or a stale copy of the row an earlier call
+//     wrote to the same place, is recognised (the walk polls its string's row until the stamp fits: walk_core.h).  So nothing here has to
+//     WAIT for a row to reach memory before it says that the row is done (waiting for the store and a returning atomic cost every wave 3 us
+//     of its ~20: the gated pass took 3.85 ms against 3.45 without, more than the seven launch tails it saves).
+//   * a wave counts its string with ONE fire-and-forget atomic in the counter of (group, string number modulo 64): 64 counters per
+//     group, each on a 64-byte line of its own (one counter per group took every string's atomic to ONE address: 12 ns each, 14.5 ms a step).
+//   * gate_wait_kernel, one wave launched on the walk stream in front of a group's walk launches, polls the group's 64 counters and
+//     ends when they are complete: the walks follow in stream order.  (The command processor can do that wait itself --
+//     hipStreamWaitValue32 -- but only on signal memory, which lives on the host side of the link: an atomic there is 0.5 us, per
+//     string 630 ms a step.)
+// What the kernel needs sits in front of the table, so that no kernel argument stays alive through the row loop (a scalar more there is a
+// VGPR more: spilled scalars live in VGPR lanes, and the kernel has 40).  u64 words, k < MFA_GATE_MAX_GROUPS:
+//   table[-1 - k]   exclusive end of group k (string index; the last group's is n, unused ones ~0)
+//   table[-33]      the call's stamp, already in place (stamp << 52)
+//   below table[-96]: the counters, (k, r) at 64-byte line k * 64 + r + 1 going down; zeroed by the host before the launch
+__device__ __forceinline__ uint32_t* gate_counter(const uint64_t* table, uint32_t k, uint32_t r) {
+    return const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(table - MFA_GATE_FIXED_WORDS)) - 16u * (k * 64u + r + 1u);
+}
+// strings of [lo, hi) whose number is r modulo 64
+__device__ __forceinline__ uint32_t gate_share(uint64_t lo, uint64_t hi, uint32_t r) { return (uint32_t)(((hi + 63u - r) >> 6) - ((lo + 63u - r) >> 6)); }
+
+__device__ __forceinline__ void gate_signal(const uint64_t* table, uint64_t sid, uint32_t lane) {
+    uint32_t k = 0;
+    while (k + 1u < MFA_GATE_MAX_GROUPS && sid >= table[-1 - (int)k]) k++;      // (scalar loads; groups are few)
+    if (lane == 0) __hip_atomic_fetch_add(gate_counter(table, k, (uint32_t)sid & 63u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// one wave: ends when every string of group k has been counted (or after two seconds: a walk that then meets a row without the
+// call's stamp polls it for a while and goes on without the row -- slower, never wrong)
+__global__ void __launch_bounds__(64) gate_wait_kernel(const uint64_t* table, uint32_t k) {
+    const uint32_t r = threadIdx.x & 63u;
+    const uint64_t hi = table[-1 - (int)k], lo = k ? table[-(int)k] : 0ull;
+    const uint32_t mine = gate_share(lo, hi, r);
+    const uint32_t* const c = gate_counter(table, k, r);
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const uint32_t v = __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__all(v >= mine)) break;
+        if (wall_clock64() - t0 > 200000000ull) break;                 // 100 MHz: 2 s
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
+
+int launch_gate_wait(const uint64_t* d_table, uint32_t group, void* stream) {
+    hipLaunchKernelGGL(gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_table, group);
+    HIP_TRY(hipGetLastError());
+    return MFA_OK;
 }
 
 // ---- kernels ---------------------------------------------------------------------------------------------------
@@ -471,7 +553,7 @@ constexpr int kRegionDepth = 2;      // 3 and 4 are more robust alone at low occ
 // before the current string's candidates are resolved) was built and measured: 4.48 ms against 4.30 ms for this one on the
 // headline shard, and worse beside the walk kernels -- with eight waves per SIMD the dispatcher's own refill hides a wave's
 // start-up latencies as well as software pipelining does.
-template <int MODE, int DEPTH, bool SAFE>
+template <int MODE, int DEPTH, bool SAFE, bool GATE = false>
 __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t n,
                                                              uint64_t* __restrict__ table, uint32_t rotate) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -487,10 +569,19 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
     // still every string exactly once.)
     uint64_t first = wave;
     if (rotate && (wave | 63ull) < n) first = (wave & ~63ull) | ((wave + 17ull * (wave >> 6)) & 63ull);
-    for (uint64_t sid = first; sid < n; sid += n_waves) {
+    // (with the gate the grid has a wave for every string: no second trip, and nothing that only the next trip needs stays alive)
+    for (uint64_t sid = first; sid < n; sid += GATE ? n : n_waves) {
         const uint64_t b = offsets[sid], e = offsets[sid + 1];
         uint64_t* const tab = table + sid * MFA_REGION_WORDS;
-        if (e - b > kMaxLen) { if (lane == 0) tab[0] = MFA_REGION_OVERFLOW; continue; }
+        static_assert(kMaxLen == 0x00ffffffu, "the test below is a shift");
+        // (the shift is written out: as `e - b > kMaxLen` the test is a 64-bit VECTOR comparison whose constant sits in two vector registers
+        // through the whole kernel -- the scalar unit has no 64-bit less-than --, and the compiler turns a shift it can see back into that)
+        uint64_t over;
+        asm("s_lshr_b64 %0, %1, 24" : "=s"(over) : "s"(e - b) : "scc");
+        if (!GATE && over != 0ull) { if (lane == 0) tab[0] = MFA_REGION_OVERFLOW; continue; }
+        // (with the gate a string beyond the limit takes the common way out -- no rows, a header that says overflow --: its own store would
+        // keep its constant operands in vector registers through the whole kernel)
+        const bool too_long = GATE && over != 0ull;
         const Geo g = make_geo(b, e, ymax);
         const uint8_t* const sbase = bytes + g.a0;
         Scan sc;
@@ -501,7 +592,7 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
         Row r[DEPTH];
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) { r[k].x = u32x4{0, 0, 0, 0}; r[k].y = u32x2{0, 0}; }
-        bool more = g.nrows > 0;
+        bool more = g.nrows > 0 && !too_long;
         if (more) {
 #pragma unroll
             for (int k = 0; k < DEPTH - 1; k++) row_request(sbase, g, k, lane, r[k]);
@@ -522,11 +613,14 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
 #pragma unroll
         for (int k = 0; k < DEPTH; k++) row_wait_all(r[k]);             // nothing of this string is in flight any more
         if (MODE == 1) { if (lane == 0) tab[0] = sc.st.ncand; continue; }
-        finish_string(sc, lane, g, bytes, total16, tab);
+        RowOut ro = finish_string(sc, lane, g, bytes, total16);
+        if (too_long) { ro.entry = false; ro.header = MFA_REGION_OVERFLOW; }
+        row_out<GATE>(tab, lane, ro, GATE ? table[-33] : 0ull);
+        if (GATE) gate_signal(table, sid, lane);
     }
 }
 
-int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream, unsigned threads) {
+int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream, unsigned threads, bool gate) {
     if (n == 0) return MFA_OK;
     hipStream_t s = (hipStream_t)stream;
     const char* em = getenv("MFA_REGION_MODE");                   // development knobs
@@ -538,7 +632,9 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     const unsigned block = eb && (atoi(eb) == 64 || atoi(eb) == 128 || atoi(eb) == 256) ? (unsigned)atoi(eb) : (threads == 128u ? 128u : 256u);
     const uint64_t wpb = block / 64u;
     uint64_t blocks = (n + wpb - 1) / wpb;
-    const uint64_t cap = cus * 8u * 64u * (4u / wpb);             // beyond this waves take several strings each
+    // beyond this waves take several strings each.  Not with the gate: there a wave takes ONE string, so that strings are finished in about
+    // the order of their numbers (the dispatcher hands out workgroups in order) and the groups' counters fill up one after the other
+    const uint64_t cap = gate ? 0x7fffffffull : cus * 8u * 64u * (4u / wpb);
     if (blocks > cap) blocks = cap;
     const char* el = getenv("MFA_REGION_LDS");                    // development: unused dynamic LDS per workgroup, to lower the occupancy
     const unsigned lds = el ? (unsigned)atoi(el) : 0u;
@@ -550,7 +646,8 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     const uint32_t rotate = er && er[0] == '0' ? 0u : 1u;
     const char* es = getenv("MFA_REGION_SAFE_WAITS");
     const bool safe = es && es[0] == '1';
-    if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
+    if (gate) hipLaunchKernelGGL((region_scan_kernel<0, 2, false, true>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
+    else if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else if (safe) hipLaunchKernelGGL((region_scan_kernel<0, 2, true>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);

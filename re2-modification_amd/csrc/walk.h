@@ -25,6 +25,7 @@ struct WalkArgs {                     // kernel parameters; every pointer is a d
     uint32_t table_words, shared_words;      // LDS words: the tables, and the tables rounded up to a multiple of 64
     uint32_t n_seg, C, CX, accel, refill;
     uint32_t images_global;           // the two probe images of a lane live in global memory (less LDS per wave: more waves per CU)
+    uint32_t gate;                    // 0, or 0x1000 | stamp: the region table is being written while the kernel runs, rows carry this stamp (regions.hip: GATE)
     uint32_t seg_first[WALK_MAX_SEG + 1];    // segment s = strings seg_first[s] .. seg_first[s+1]-1 of this launch ...
     uint32_t seg_table[WALK_MAX_SEG];        // ... walks the automaton whose table block starts at this word of `tables`
 };

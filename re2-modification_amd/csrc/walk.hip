@@ -74,7 +74,7 @@ walk_kernel(WalkArgs a) {
     st.gsb = g; g += XI * W * 64u;
     st.gsa = g; g += XI * DW * 64u;
     st.gq = g;
-    Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.refill, a.n_seg, a.seg_first, a.seg_table};
+    Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.refill, a.n_seg, a.seg_first, a.seg_table, a.gate};
     TicketFeeder feed{a.counter, a.n, gwave * 64u};
 #if WALK_STATS
     // development build: per-lane counts and per-wave cycle counts, added up in a.counter[8 ..]

@@ -73,6 +73,8 @@ static unsigned long long g_ev[8];      // development counts: entries, edge eva
 #define WALK_EV(k) (g_ev[k]++)
 WALK_DEV uint32_t wv_lane() { return 0u; }
 WALK_DEV uint64_t wv_shfl64(uint64_t v, int) { return v; }
+WALK_DEV uint64_t wv_load_fresh(const uint64_t* p) { return *p; }
+WALK_DEV void wv_nap() {}
 // the wave-wide scans of device_common.h assume 64 lanes: scalar restatements for the one-lane wave
 template <bool REV>
 inline uint32_t coop_run_end_x(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t) {
@@ -91,6 +93,9 @@ inline bool coop_mem_equal_x(const uint8_t* bytes, uint64_t pa, uint64_t pb, uin
 #else
 #define WALK_EV(k) ((void)0)
 WALK_DEV uint32_t wv_lane() { return threadIdx.x & 63u; }
+// a load that does not take this CU's L1 copy for an answer (agent scope: `sc1`), and a pause between two polls
+WALK_DEV uint64_t wv_load_fresh(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+WALK_DEV void wv_nap() { __builtin_amdgcn_s_sleep(16); }
 WALK_DEV uint64_t wv_shfl64(uint64_t v, int L) { return ((uint64_t)__shfl((uint32_t)(v >> 32), L) << 32) | __shfl((uint32_t)v, L); }
 // Out of line on purpose: a scan is rare (a run the region table does not hold, a long comparison outside known regions), sits in
 // the innermost loop of the step, and inlined it raised the kernel's register count by 25 for every wave, scanning or not.
@@ -116,6 +121,8 @@ struct WIn {
     const uint8_t*  bytes;       // wave-uniform: the whole batch
     uint64_t        total16;     //   its size rounded up to 16: loads stay below this offset
     const uint64_t* regions;     //   region table of the launch (regions.hip), nullptr = none
+    uint32_t gate;               //   0, or 0x1000 | the stamp every word of this call's table rows carries (bits 52..63): the table is being written
+                                 //   while this kernel runs (regions.hip: GATE), a word without the stamp has not arrived yet or is a stale copy
     WALK_LDS uint64_t* rtc;      //   the wave's LDS copy of every lane's first MFA_RT_CACHED table entries, [entry][lane]
     uint64_t base;               // offset of this lane's string
     uint32_t len, sid;
@@ -140,6 +147,28 @@ WALK_DEV void w_reset(WIn& in, uint64_t base, uint32_t len, uint32_t sid) {
     in.per_lo = in.per_hi = 0; in.per_q = 0; in.dual_p = 0;
     in.prev_lo = in.prev_hi = 0; in.prev_q = 0;
     in.rt_cnt = 0; in.rq = 0; in.rq_a = in.rq_b = in.rq_l = 0; in.cq_n = 0;
+}
+
+// Gated launches (in.gate != 0): the row's header and its first MFA_RT_CACHED entries must carry the call's stamp.  A lane whose row does
+// not (yet) polls it -- fresh loads, a pause between two -- and gives up after ~50 ms: it then walks without a table (slower, never wrong).
+WALK_DEV bool w_rt_stamped(const WIn& in, const uint4 a, const uint4 b) {
+    const uint32_t want = in.gate & 0xfffu, cnt = a.x & 0xffu;
+    return (a.y >> 20) == want && (cnt < 1u || (a.w >> 20) == want) && (cnt < 2u || (b.y >> 20) == want);
+}
+WALK_DEV void w_rt_await(const WIn& in, bool mine, uint64_t sid, uint4& a, uint4& b) {
+    if (in.gate == 0u || in.regions == nullptr) return;
+    bool ok = !mine || w_rt_stamped(in, a, b);
+    for (uint32_t tries = 0; __any(!ok) && tries < 50000u; tries++) {
+        if (!ok) {
+            const uint64_t* t = in.regions + sid * MFA_RT_WORDS;
+            const uint64_t w0 = wv_load_fresh(t), w1 = wv_load_fresh(t + 1), w2 = wv_load_fresh(t + 2);
+            a = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+            b = make_uint4((uint32_t)w2, (uint32_t)(w2 >> 32), 0u, 0u);
+            ok = w_rt_stamped(in, a, b);
+        }
+        if (__any(!ok)) wv_nap();
+    }
+    if (!ok) a = b = make_uint4(0, 0, 0, 0);
 }
 
 // The table row of the lane's string: header and first MFA_RT_CACHED entries arrive in (a, b) (two 16-byte loads that go out
@@ -169,7 +198,13 @@ WALK_DEV void w_rt_attach(WIn& in, uint32_t& warm, const uint4 a, const uint4 b)
 // entry e in scan coordinates
 template <bool REV>
 WALK_DEV void w_rt_entry(const WIn& in, uint32_t e, uint32_t& lo, uint32_t& hi, uint32_t& q) {
-    const uint64_t w = e < MFA_RT_CACHED ? in.rtc[e * WALK_WV + wv_lane()] : in.regions[(uint64_t)in.sid * MFA_RT_WORDS + 1u + e];
+    uint64_t w;
+    if (e < MFA_RT_CACHED) w = in.rtc[e * WALK_WV + wv_lane()];
+    else if (in.gate == 0u) w = in.regions[(uint64_t)in.sid * MFA_RT_WORDS + 1u + e];
+    else {                                                       // past this CU's L1 (which may hold the row an earlier call wrote), and only with the call's stamp
+        w = wv_load_fresh(in.regions + (uint64_t)in.sid * MFA_RT_WORDS + 1u + e);
+        if ((uint32_t)(w >> 52) != (in.gate & 0xfffu)) w = 0ull;      // (not there: the lane walks that stretch step by step)
+    }
     const uint32_t mlo = (uint32_t)w & 0x00ffffffu, mhi = (uint32_t)(w >> 24) & 0x00ffffffu;
     q = (uint32_t)(w >> 48) & 15u;
     lo = REV ? in.len - mhi : mlo;
@@ -522,10 +557,10 @@ template <bool REV> inline
 #else
 template <bool REV> __device__ __attribute__((noinline))
 #endif
-RunEnd run_end_for(const uint8_t* bytes, uint64_t total16, const uint64_t* regions, WALK_LDS uint64_t* rtc, uint64_t base, uint32_t len, uint32_t sid,
+RunEnd run_end_for(const uint8_t* bytes, uint64_t total16, const uint64_t* regions, uint32_t gate, WALK_LDS uint64_t* rtc, uint64_t base, uint32_t len, uint32_t sid,
                    uint32_t rt_cnt, bool nr, uint32_t i, uint32_t ch) {
     WIn in;
-    in.bytes = bytes; in.total16 = total16; in.regions = regions; in.rtc = rtc; in.base = base; in.len = len; in.sid = sid; in.rt_cnt = rt_cnt;
+    in.bytes = bytes; in.total16 = total16; in.regions = regions; in.gate = gate; in.rtc = rtc; in.base = base; in.len = len; in.sid = sid; in.rt_cnt = rt_cnt;
     RunEnd out{0u, false};
     const uint32_t lane = wv_lane();
     if (nr && regions != nullptr) {
@@ -616,7 +651,7 @@ WALK_DEV void answer_requests(const Store& st, WIn& in, bool active) {
     {
         const bool nr = active && in.rq == 1u;
         if (__any(nr)) {
-            const RunEnd re = run_end_for<REV>(in.bytes, in.total16, in.regions, in.rtc, in.base, in.len, in.sid, in.rt_cnt, nr, in.rq_a, in.rq_b);
+            const RunEnd re = run_end_for<REV>(in.bytes, in.total16, in.regions, in.gate, in.rtc, in.base, in.len, in.sid, in.rt_cnt, nr, in.rq_a, in.rq_b);
             if (nr) {
                 in.run_lo = in.rq_a; in.run_hi = re.end; in.run_ch = in.rq_b;
                 // a measured run is a periodic region too (unless one that reaches at least as far is known: a probe may rely on it)
@@ -954,6 +989,7 @@ struct Batch {
     uint32_t n_seg;              // segments of the batch: strings seg_first[s] .. seg_first[s+1]-1 belong to the automaton whose tables
     const uint32_t* seg_first;   //   start at word seg_table[s] of the table block (n_seg + 1 / n_seg entries, 32-bit string indices)
     const uint32_t* seg_table;
+    uint32_t gate;               // WIn::gate
 };
 
 struct WaveStats {
@@ -1024,7 +1060,7 @@ struct ShapeHist {
 template <int K, bool REV, class Feeder, class TP>
 WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t* rt_cache, Feeder& feed, WaveStats* stats) {
     WIn in;
-    in.bytes = b.bytes; in.total16 = (b.offsets[b.n] + 15u) & ~(uint64_t)15; in.regions = b.regions; in.rtc = rt_cache;
+    in.bytes = b.bytes; in.total16 = (b.offsets[b.n] + 15u) & ~(uint64_t)15; in.regions = b.regions; in.rtc = rt_cache; in.gate = b.gate;
     w_reset(in, 0, 0, 0);
     in.w0 = in.w1 = in.w2 = in.w3 = 0;
     bool active = false, exhausted = false, accept = false;
@@ -1052,12 +1088,13 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
             if (wantb && ((uint32_t)__builtin_popcountll(wantb) >= b.refill || !__any(active))) {
                 uint64_t s = 0;
                 const bool got = feed.take(want, s);
+                uint4 rta = make_uint4(0, 0, 0, 0), rtb = rta;
+                if (want && got) rt_fetch(b.regions, s, rta, rtb);   // the table row and the offsets travel together
+                if (b.gate != 0u) w_rt_await(in, want && got, s, rta, rtb);      // (the row is being written while this kernel runs: not without the call's stamp)
                 if (want) {
                     if (!got) exhausted = true;
                     else {
                         const uint64_t sid = s;
-                        uint4 rta, rtb;
-                        rt_fetch(b.regions, sid, rta, rtb);          // the table row and the offsets travel together
                         const uint64_t o0 = b.offsets[sid], o1 = b.offsets[sid + 1];
                         if (o1 - o0 > MFA_DEV_MAX_LEN) b.results[sid] = 2;
                         else {

@@ -43,7 +43,7 @@ static size_t wave_words(uint32_t K, uint32_t C, bool ig) {
 // longest possible list if that leaves room for two workgroups per CU, else what does (longer lists spill to `d_spill`).
 int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                 uint8_t* d_results, const uint64_t* d_regions, uint32_t n_seg, const uint32_t* seg_first, const uint32_t* seg_table,
-                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream) {
+                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate) {
     if (n == 0) return MFA_OK;
     if (n_seg == 0 || n_seg > WALK_MAX_SEG || n > 0xffffffffull) return MFA_ERR_INVALID_ARG;
     WalkLaunch L;
@@ -51,6 +51,7 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     std::memset(&a, 0, sizeof a);
     a.bytes = d_bytes; a.offsets = d_offsets; a.n = n; a.results = d_results; a.regions = d_regions; a.tables = d_tables;
     a.counter = d_counter;
+    a.gate = gate;
     a.table_words = p.table_words;
     a.shared_words = (p.table_words + 63u) & ~63u;
     // tables beyond a third of the LDS (or forced: development) stay in global memory
@@ -84,10 +85,17 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     if (cap_waves > 0 && (uint64_t)(cap_waves + 3) / 4 < per_cu) per_cu = (uint64_t)(cap_waves + 3) / 4;
     uint64_t grid = (uint64_t)(n_cus > 0 ? n_cus : 256) * per_cu, want = (n + 255) / 256;
     if (grid > want) grid = want;
+    // What a wave may spill (list entries and probe images beyond the LDS capacity) is sized for the worst case -- every node of the launch's
+    // largest automaton alive at once -- per wave of the grid: 4.7 MB per wave for 1024 nodes and one cell.  The grid shrinks (the waves are
+    // persistent: fewer of them take more tickets each) until that fits a budget, 2 GiB by default; what does not fit with ONE workgroup is MFA_ERR_NOMEM.
+    const uint32_t W = 2 + 2 * p.K, DW = (1 + 2 * p.K + 1) / 2;
+    const size_t per_wave = ((size_t)(a.CX + a.C) * 64u * (3u * W + 3u * DW) + 4u * 4u * 64u) * sizeof(uint32_t);      // + the comparison answers (walk_core.h: CMP_CACHE)
+    const size_t budget = (size_t)std::max(1, env_int("MFA_WALK_SPILL_MB", 2048)) << 20;
+    while (grid > 1 && grid * 4u * per_wave > budget) grid = (grid + 1) / 2;
+    if (grid * 4u * per_wave > budget) return MFA_ERR_NOMEM;
     L.grid = (unsigned)grid;
     L.reversed = p.reversed;
-    const uint32_t W = 2 + 2 * p.K, DW = (1 + 2 * p.K + 1) / 2;
-    const size_t need = (size_t)grid * 4u * ((size_t)(a.CX + a.C) * 64u * (3u * W + 3u * DW) + 4u * 4u * 64u) * sizeof(uint32_t);      // + the comparison answers (walk_core.h: CMP_CACHE)
+    const size_t need = (size_t)grid * 4u * per_wave;
     int rc = ctx_reserve((void**)d_spill, spill_bytes, need);
     if (rc != MFA_OK) return rc;
     a.spill = *d_spill;
@@ -153,6 +161,13 @@ struct mfa_mixed {
         uint32_t* d_spill[MIX_MAX_LAUNCHES] = {nullptr}; size_t spill_bytes[MIX_MAX_LAUNCHES] = {0};
         unsigned long long* d_counters = nullptr;
         int n_cus = 0;
+        // the gate: ONE region launch per call; in front of a group's walk launches, on their stream, one wave that ends when the region
+        // kernel has counted every string of the group (regions.hip: GATE)
+        int gate_state = 0;                                    // 0 not tried, 1 usable, -1 not
+        uint64_t* h_hdr = nullptr;                             // pinned: the gate headers of the last MIX_TIMINGS calls
+        hipEvent_t ev_clear = nullptr;
+        uint32_t last_region_launches = 0, last_walk_launches = 0, last_groups = 0;
+        bool last_gated = false;
         bool timed = false, calibrated = false;
         std::vector<float> cost;                               // per segment: its walk alone, ms
         float ready[MIX_MAX_GROUPS] = {0};                     // per group: end of its region launch, ms from the start of the call
@@ -205,6 +220,8 @@ void mfa_mixed_destroy(mfa_mixed_t* mx) {
         if (d.d_regions) (void)hipFree(d.d_regions);
         for (uint32_t* p : d.d_spill) if (p) (void)hipFree(p);
         if (d.d_counters) (void)hipFree(d.d_counters);
+        if (d.h_hdr) (void)hipHostFree(d.h_hdr);
+        if (d.ev_clear) (void)hipEventDestroy(d.ev_clear);
         for (hipEvent_t e : d.ev_g) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : d.ev_w) if (e) (void)hipEventDestroy(e);
         if (d.ev_in) (void)hipEventDestroy(d.ev_in);
@@ -237,6 +254,7 @@ static int mixed_device(mfa_mixed* mx, int device, mfa_mixed::Dev** out) {
     for (hipEvent_t& e : d.ev_g) HIP_TRY(hipEventCreate(&e));
     for (hipEvent_t& e : d.ev_w) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&d.ev_in, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&d.ev_clear, hipEventDisableTiming));
     for (uint32_t k = 0; k < MIX_TIMINGS; k++) { HIP_TRY(hipEventCreate(&d.ev_r0[k])); HIP_TRY(hipEventCreate(&d.ev_r1[k])); HIP_TRY(hipEventCreate(&d.ev_end[k])); }
     d.cost.assign(mx->images.size(), 0.0f);
     auto ins = mx->dev.emplace(device, d);
@@ -244,10 +262,23 @@ static int mixed_device(mfa_mixed* mx, int device, mfa_mixed::Dev** out) {
     return MFA_OK;
 }
 
+// Is the gate usable on this device?  Decided once.
+static bool gate_ready(mfa_mixed::Dev& d) {
+    if (d.gate_state != 0) return d.gate_state > 0;
+    d.gate_state = -1;
+    if (hipHostMalloc((void**)&d.h_hdr, MIX_TIMINGS * MFA_GATE_FIXED_WORDS * sizeof(uint64_t), hipHostMallocDefault) != hipSuccess) { d.h_hdr = nullptr; (void)hipGetLastError(); return false; }
+    d.gate_state = 1;
+    return true;
+}
+
+// What a call will launch, decided before anything is put on a stream (an error found here leaves the streams untouched).
+struct MixLaunch { uint32_t g, s0, s1, ml, Kc, w0, w1; uint64_t a, b; int k; };
+
 // seg_first: HOST array of n_images + 1 string indices, seg_first[0] = 0, seg_first[n_images] = n: strings seg_first[s] ..
 // seg_first[s+1]-1 are matched against images[s] (the order of mfa_mixed_create).  `stream` sees the call as one operation.
-int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const uint64_t* seg_first,
-                    uint8_t* d_results, int device, void* stream) {
+// total_bytes: offsets[n] - offsets[0] if the caller knows it, else 0 (then it is read back once per string count: see the header).
+static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const uint64_t* seg_first,
+                            uint8_t* d_results, int device, void* stream, uint64_t total_bytes) {
     if (!mx || !d_offsets || !seg_first || (!d_results && n)) return MFA_ERR_INVALID_ARG;
     const uint32_t ns = (uint32_t)mx->images.size();
     if (seg_first[0] != 0 || seg_first[ns] != n) return MFA_ERR_INVALID_ARG;
@@ -268,21 +299,24 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
         // (a walk is latency-bound: ~0.3-0.5 ms for 20 000 strings as for 200 000): 1.3 GB per group, eight groups at most (measured: 10.7 GB of
         // 64 KiB strings 2.02 ms in eight groups, 2.28 ms in four; the 19.4 GB headline batch eight).  Cut finer, a small batch pays the walks'
         // latency once per group (a 1.9 GB batch of one automaton: 1.26 ms in eight groups against 0.52 ms in one; 34 ms against 9.8 ms
-        // for the 77-node automaton).  The bytes of a batch are device data (offsets[n] - offsets[0]): they are read back ONCE per string count
-        // this object meets -- that call waits for the caller's stream -- and remembered.
+        // for the 77-node automaton).  The bytes of a batch are device data (offsets[n] - offsets[0]): a caller that knows them says so
+        // (mfa_match_mixed_sized); otherwise they are read back ONCE per string count this object meets -- that call waits for the
+        // caller's stream -- and remembered (a later batch with the same count and other bytes gets the same grouping: a matter of speed only).
         const char* spec = getenv("MFA_MIXED_CUTS");
         std::string made;
         if (!spec) {
-            uint64_t bytes = 0;
+            uint64_t bytes = total_bytes;
             auto known = mx->bytes_of.find(n);
-            if (known != mx->bytes_of.end()) bytes = known->second;
+            if (bytes != 0) { /* the caller's word */ }
+            else if (known != mx->bytes_of.end()) bytes = known->second;
             else if (n >= 65536) {
                 uint64_t ends[2] = {0, 0};
                 HIP_TRY(hipMemcpyAsync(&ends[0], d_offsets, sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
                 HIP_TRY(hipMemcpyAsync(&ends[1], d_offsets + n, sizeof(uint64_t), hipMemcpyDeviceToHost, cs));
                 HIP_TRY(hipStreamSynchronize(cs));
                 bytes = ends[1] - ends[0];
-                if (mx->bytes_of.size() < 64) mx->bytes_of[n] = bytes;
+                if (mx->bytes_of.size() >= 64) mx->bytes_of.clear();
+                mx->bytes_of[n] = bytes;
             }
             const double per_group = table ? 1.3e9 : 2.0e9;
             const uint32_t most = table ? 8u : 5u;
@@ -311,13 +345,50 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
     const char* re = getenv("MFA_REGIONS");
     const char* ae = getenv("MFA_ACCEL");
     const bool with_regions = !(re && re[0] == '0') && !(ae && ae[0] == '0');
-    if (with_regions) {
-        rc = ctx_reserve((void**)&d->d_regions, &d->region_bytes, (size_t)n * MFA_REGION_WORDS * sizeof(uint64_t));
-        if (rc != MFA_OK) return rc;
-    }
     int NW = env_int("MFA_MIXED_WALK_STREAMS", table ? 2 : 3);
     if (NW < 1) NW = 1;
     if (NW > (int)MIX_MAX_STREAMS) NW = MIX_MAX_STREAMS;
+    // ONE region launch for the whole batch and the walks released group by group (the gate): table engine, more than one group.
+    // Built, checked (tests/test_regions_gpu.py::test_gated_walks_see_fresh_tables) and measured in round 4 -- and NOT the default: it saves
+    // seven region launches, and the step takes as long or longer (4.29 against 3.84-4.18 ms on one box; kernel traces in
+    // profiles/r04d_trace_*.txt).  What a launch's ramp and tail leave idle, the walk kernels beside it use: with one launch the walks take
+    // 5.3 ms of stream time instead of 4.2, the region pass 3.83 ms instead of 3.9 for its eight launches.  MFA_MIXED_GATE=1 turns it on.
+    const bool gate = table && with_regions && ng > 1 && ng <= MFA_GATE_MAX_GROUPS && env_int("MFA_MIXED_GATE", 0) != 0 && gate_ready(*d);
+    const uint32_t stamp = (uint32_t)(d->calls & 0xfffu);     // what every word of this call's table rows carries (the table buffer is rewritten by every call)
+
+    // ---- the plan (table engine): one launch per group and run of consecutive segments whose automata have the same number of cells (a
+    // launch's kernel and its LDS footprint are those of its largest cell count); groups alternate between the walk streams, so that a
+    // group's walk may start while the one before it drains
+    std::vector<MixLaunch> plan;
+    if (table)
+        for (uint32_t g = 0; g < ng; g++) {
+            const uint64_t lo = cut[g], hi = cut[g + 1];
+            uint32_t sa = 0;
+            while (sa + 1 < ns && seg_first[sa + 1] <= lo) sa++;
+            uint32_t sb = sa;
+            while (sb < ns && seg_first[sb] < hi) sb++;
+            for (uint32_t s0 = sa; s0 < sb;) {
+                uint32_t s1 = s0 + 1;
+                const uint32_t Kc = mx->K > 6 ? mx->K : mx->images[s0]->walk.K;
+                while (s1 < sb && s1 - s0 < WALK_MAX_SEG && (mx->K > 6 || mx->images[s1]->walk.K == Kc)) s1++;
+                const uint64_t a = std::max(seg_first[s0], lo), b = std::min(seg_first[s1], hi);
+                if (b > a) {
+                    uint32_t ml = 1;
+                    for (uint32_t j = s0; j < s1; j++) ml = std::max(ml, mx->images[j]->walk.max_live);
+                    // the launch gets the blocks of ITS automata only (they lie back to back): less LDS per workgroup
+                    plan.push_back(MixLaunch{g, s0, s1, ml, Kc, mx->block_at[s0], s1 < ns ? mx->block_at[s1] : (uint32_t)mx->words.size(), a, b, (int)(g % (uint32_t)NW)});
+                }
+                s0 = s1;
+            }
+        }
+    if (plan.size() > MIX_MAX_LAUNCHES) return MFA_ERR_UNSUPPORTED;      // (more runs of equal cell count than the object has launch slots: nothing was started)
+    uint64_t* d_table = nullptr;
+    if (with_regions) {
+        const size_t head = gate ? MFA_GATE_HEADER_WORDS : 0;
+        rc = ctx_reserve((void**)&d->d_regions, &d->region_bytes, ((size_t)n * MFA_REGION_WORDS + MFA_GATE_HEADER_WORDS) * sizeof(uint64_t));
+        if (rc != MFA_OK) return rc;
+        d_table = d->d_regions + head;
+    }
     // which stream walks which segment (generated kernels): first call one after the other (timed), then by cost
     std::vector<int> where(ns, 0);
     const bool calibrating = !table && !d->calibrated;
@@ -333,104 +404,150 @@ int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_o
             where[s] = best;
         }
     }
-    HIP_TRY(hipEventRecord(d->ev_in, cs));
-    HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_in, 0));
-    for (int k = 0; k < NW; k++) {
+    for (int k = 0; k < NW; k++)
         if (!d->ws[k]) {
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
             if (env_int("MFA_MIXED_WALK_PRIORITY", 0) != 0) HIP_TRY(hipStreamCreateWithPriority(&d->ws[k], hipStreamNonBlocking, greatest));
             else HIP_TRY(hipStreamCreateWithFlags(&d->ws[k], hipStreamNonBlocking));
         }
-        HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_in, 0));
-    }
     const uint32_t slot_t = (uint32_t)(d->calls % MIX_TIMINGS);
+
+    // ---- from here on work goes to the internal streams.  Whatever happens, the caller's stream is made to wait for all of it before this
+    // function returns: a caller that gets an error may free or reuse its buffers in stream order like one that gets MFA_OK.
+    struct Join {
+        mfa_mixed::Dev* d; hipStream_t cs; int NW; uint32_t slot_t; bool used[MIX_MAX_STREAMS] = {false}; bool started = false; int err = MFA_OK;
+        void run() {
+            if (!started) return;
+            started = false;
+            for (int k = 0; k < NW; k++)
+                if (used[k]) {
+                    if (hipEventRecord(d->ev_w[k], d->ws[k]) != hipSuccess || hipStreamWaitEvent(d->rs, d->ev_w[k], 0) != hipSuccess) { err = MFA_ERR_HIP; (void)hipStreamSynchronize(d->ws[k]); }
+                }
+            if (hipEventRecord(d->ev_end[slot_t], d->rs) != hipSuccess || hipStreamWaitEvent(cs, d->ev_end[slot_t], 0) != hipSuccess) { err = MFA_ERR_HIP; (void)hipStreamSynchronize(d->rs); }
+        }
+        ~Join() { run(); }
+    } join{d, cs, NW, slot_t};
+    HIP_TRY(hipEventRecord(d->ev_in, cs));
+    HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_in, 0));
+    join.started = true;
+    if (gate) {
+        // the gate header in front of the table (regions.hip: gate_signal), the counters back to zero; the walk streams start behind both
+        uint64_t* h = d->h_hdr + (size_t)slot_t * MFA_GATE_FIXED_WORDS;
+        for (uint32_t k = 0; k < MFA_GATE_FIXED_WORDS; k++) h[k] = 0ull;
+        for (uint32_t k = 0; k < MFA_GATE_MAX_GROUPS; k++) h[MFA_GATE_FIXED_WORDS - 1 - k] = k < ng ? cut[k + 1] : ~0ull;
+        h[MFA_GATE_FIXED_WORDS - 33] = (uint64_t)stamp << 52;
+        HIP_TRY(hipMemsetAsync(d->d_regions, 0, (MFA_GATE_HEADER_WORDS - MFA_GATE_FIXED_WORDS) * sizeof(uint64_t), d->rs));      // the counters
+        HIP_TRY(hipMemcpyAsync(d->d_regions + (MFA_GATE_HEADER_WORDS - MFA_GATE_FIXED_WORDS), h, MFA_GATE_FIXED_WORDS * sizeof(uint64_t), hipMemcpyHostToDevice, d->rs));
+        HIP_TRY(hipEventRecord(d->ev_clear, d->rs));
+    }
+    for (int k = 0; k < NW; k++) HIP_TRY(hipStreamWaitEvent(d->ws[k], gate ? d->ev_clear : d->ev_in, 0));
     HIP_TRY(hipEventRecord(d->ev_r0[slot_t], d->rs));
-    bool used[MIX_MAX_STREAMS] = {false};
-    uint32_t slot = 0;                                        // table engine: launches of this call
+    uint32_t region_launches = 0;
+    if (gate) {
+        rc = launch_region_scan(d->n_cus, d_bytes, d_offsets, n, d_table, d->rs, 128u, true);
+        if (rc != MFA_OK) return rc;
+        region_launches = 1;
+    }
+    uint32_t slot = 0;
     for (uint32_t g = 0; g < ng; g++) {
         const uint64_t lo = cut[g], hi = cut[g + 1];
-        hipStream_t rg = d->rs;
-        if (with_regions) {
-            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d->d_regions + lo * MFA_REGION_WORDS, rg, table ? 128u : 256u);
+        if (with_regions && !gate) {
+            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d_table + lo * MFA_REGION_WORDS, d->rs, table ? 128u : 256u);
             if (rc != MFA_OK) return rc;
+            region_launches++;
         }
-        HIP_TRY(hipEventRecord(d->ev_g[g], rg));
-        const uint64_t* tab = with_regions ? d->d_regions : nullptr;
-        // the segments that overlap this group
-        uint32_t sa = 0;
-        while (sa + 1 < ns && seg_first[sa + 1] <= lo) sa++;
-        uint32_t sb = sa;
-        while (sb < ns && seg_first[sb] < hi) sb++;
+        if (!gate) HIP_TRY(hipEventRecord(d->ev_g[g], d->rs));
         bool waits[MIX_MAX_STREAMS] = {false};
+        // a stream's first launch of this group waits for the group's regions: for the event behind its region launch, or -- with the gate -- for
+        // one wave, launched in front of it, that ends when the region kernel has counted every string of the group
+        auto release = [&](int k) -> int {
+            if (waits[k]) return MFA_OK;
+            waits[k] = true;
+            if (gate) { join.used[k] = true; return launch_gate_wait(d_table, g, d->ws[k]); }
+            HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_g[g], 0));
+            return MFA_OK;
+        };
         if (table) {
-            // one launch per run of consecutive segments whose automata have the same number of cells (a launch's kernel and its LDS
-            // footprint are those of its largest cell count); groups alternate between the walk streams, so that a group's walk may
-            // start while the one before it drains
-            const int k = (int)(g % (uint32_t)NW);
-            for (uint32_t s0 = sa; s0 < sb;) {
-                uint32_t s1 = s0 + 1;
-                const uint32_t Kc = mx->K > 6 ? mx->K : mx->images[s0]->walk.K;
-                while (s1 < sb && s1 - s0 < WALK_MAX_SEG && (mx->K > 6 || mx->images[s1]->walk.K == Kc)) s1++;
-                const uint64_t a = std::max(seg_first[s0], lo), b = std::min(seg_first[s1], hi);
-                if (b > a) {
-                    if (slot >= MIX_MAX_LAUNCHES) return MFA_ERR_UNSUPPORTED;
-                    if (!waits[k]) { HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_g[g], 0)); waits[k] = true; }
-                    uint32_t sf[WALK_MAX_SEG + 1], stb[WALK_MAX_SEG], ml = 1;
-                    for (uint32_t j = 0; j <= s1 - s0; j++) sf[j] = (uint32_t)(std::min(std::max(seg_first[s0 + j], a), b) - a);
-                    // the launch gets the blocks of ITS automata only (they lie back to back): less LDS per workgroup
-                    const uint32_t w0 = mx->block_at[s0], w1 = s1 < ns ? mx->block_at[s1] : (uint32_t)mx->words.size();
-                    for (uint32_t j = 0; j < s1 - s0; j++) { stb[j] = mx->block_at[s0 + j] - w0; ml = std::max(ml, mx->images[s0 + j]->walk.max_live); }
-                    const WalkPlanInput pk{Kc, ml, mx->reversed, w1 - w0};
-                    rc = launch_walk(pk, d->d_tables + w0, d->n_cus, d_bytes, d_offsets + a, b - a, d_results + a, tab ? tab + a * MFA_REGION_WORDS : nullptr,
-                                     s1 - s0, sf, stb, &d->d_spill[slot], &d->spill_bytes[slot], d->d_counters + 64 * slot, d->ws[k]);
-                    if (rc != MFA_OK) return rc;
-                    slot++;
-                    used[k] = true;
-                }
-                s0 = s1;
+            for (const MixLaunch& L : plan) {
+                if (L.g != g) continue;
+                rc = release(L.k);
+                if (rc != MFA_OK) return rc;
+                uint32_t sf[WALK_MAX_SEG + 1], stb[WALK_MAX_SEG];
+                for (uint32_t j = 0; j <= L.s1 - L.s0; j++) sf[j] = (uint32_t)(std::min(std::max(seg_first[L.s0 + j], L.a), L.b) - L.a);
+                for (uint32_t j = 0; j < L.s1 - L.s0; j++) stb[j] = mx->block_at[L.s0 + j] - L.w0;
+                const WalkPlanInput pk{L.Kc, L.ml, mx->reversed, L.w1 - L.w0};
+                join.used[L.k] = true;
+                rc = launch_walk(pk, d->d_tables + L.w0, d->n_cus, d_bytes, d_offsets + L.a, L.b - L.a, d_results + L.a, d_table ? d_table + L.a * MFA_REGION_WORDS : nullptr,
+                                 L.s1 - L.s0, sf, stb, &d->d_spill[slot], &d->spill_bytes[slot], d->d_counters + 64 * slot, d->ws[L.k], gate ? (0x1000u | stamp) : 0u);
+                if (rc != MFA_OK) return rc;
+                slot++;
             }
         } else {
+            uint32_t sa = 0;
+            while (sa + 1 < ns && seg_first[sa + 1] <= lo) sa++;
+            uint32_t sb = sa;
+            while (sb < ns && seg_first[sb] < hi) sb++;
             for (uint32_t s = sa; s < sb; s++) {
                 const uint64_t a = std::max(seg_first[s], lo), b = std::min(seg_first[s + 1], hi);
                 if (b <= a) continue;
                 const int k = where[s];
-                if (!waits[k]) { HIP_TRY(hipStreamWaitEvent(d->ws[k], d->ev_g[g], 0)); waits[k] = true; }
-                rc = mfa_match_batch_regions(mx->images[s], d_bytes, d_offsets + a, b - a, d_results + a, tab ? tab + a * MFA_REGION_WORDS : nullptr, device, d->ws[k]);
+                rc = release(k);
                 if (rc != MFA_OK) return rc;
-                used[k] = true;
+                join.used[k] = true;
+                rc = mfa_match_batch_regions(mx->images[s], d_bytes, d_offsets + a, b - a, d_results + a, d_table ? d_table + a * MFA_REGION_WORDS : nullptr, device, d->ws[k]);
+                if (rc != MFA_OK) return rc;
+                slot++;
             }
         }
     }
     HIP_TRY(hipEventRecord(d->ev_r1[slot_t], d->rs));
     // the caller's stream (and the call's end event, on the region stream) wait for every stream that was given work
-    for (int k = 0; k < NW; k++)
-        if (used[k]) {
-            HIP_TRY(hipEventRecord(d->ev_w[k], d->ws[k]));
-            HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_w[k], 0));
-        }
-    HIP_TRY(hipEventRecord(d->ev_end[slot_t], d->rs));
-    HIP_TRY(hipStreamWaitEvent(cs, d->ev_end[slot_t], 0));
+    join.run();
+    if (join.err != MFA_OK) return join.err;
     d->timed = true;
     d->calls++;
     d->ng_last = ng;
+    d->last_region_launches = region_launches; d->last_walk_launches = slot; d->last_groups = ng; d->last_gated = gate;
     if (calibrating) {                                        // once per device: the walks' costs and the groups' region times
         HIP_TRY(hipEventSynchronize(d->ev_end[slot_t]));
         for (uint32_t s = 0; s < ns; s++) {
             float ms = 0.0f;
             if (seg_first[s + 1] > seg_first[s] && mfa_last_kernel_ms(mx->images[s], device, &ms) == MFA_OK) d->cost[s] = ms;
         }
-        float prev = 0.0f;
         for (uint32_t g = 0; g < ng; g++) {
             // the calibration pass runs a group's walks before the next group's region launch is reached by nothing: region launches
             // follow each other on their own stream, so the elapsed time between two group events is the later group's region time
             float ms = 0.0f;
             HIP_TRY(hipEventElapsedTime(&ms, d->ev_r0[slot_t], d->ev_g[g]));
-            d->ready[g] = ms; prev = ms;
+            d->ready[g] = ms;
         }
-        (void)prev;
         d->calibrated = true;
     }
+    return MFA_OK;
+}
+
+int mfa_match_mixed(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, const uint64_t* seg_first,
+                    uint8_t* d_results, int device, void* stream) {
+    return match_mixed_impl(mx, d_bytes, d_offsets, n, seg_first, d_results, device, stream, 0);
+}
+
+int mfa_match_mixed_sized(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t total_bytes, const uint64_t* seg_first,
+                          uint8_t* d_results, int device, void* stream) {
+    return match_mixed_impl(mx, d_bytes, d_offsets, n, seg_first, d_results, device, stream, total_bytes);
+}
+
+// what the last call on `device` launched (any pointer may be NULL): region launches (1 with the gate), walk launches, groups of strings, and
+// whether the walks were released by counters (1) or by events behind per-group region launches (0)
+int mfa_mixed_last_launches(mfa_mixed_t* mx, int device, uint32_t* region_launches, uint32_t* walk_launches, uint32_t* groups, uint32_t* gated) {
+    if (!mx) return MFA_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(mx->mu);
+    auto it = mx->dev.find(device);
+    if (it == mx->dev.end() || !it->second.timed) return MFA_ERR_INVALID_ARG;
+    if (region_launches) *region_launches = it->second.last_region_launches;
+    if (walk_launches) *walk_launches = it->second.last_walk_launches;
+    if (groups) *groups = it->second.last_groups;
+    if (gated) *gated = it->second.last_gated ? 1u : 0u;
     return MFA_OK;
 }
 
@@ -457,7 +574,7 @@ int mfa_match_mixed_host(mfa_mixed_t* mx, const uint8_t* bytes, const uint64_t* 
     if (e == hipSuccess && total) e = hipMemcpy(d_bytes, bytes + offsets[0], total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_off, rel.data(), (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice);
     if (e != hipSuccess) { set_last_hip_error((int)e); rc = MFA_ERR_HIP; }
-    if (rc == MFA_OK) rc = mfa_match_mixed(mx, d_bytes, d_off, n, seg_first, d_res, device, nullptr);
+    if (rc == MFA_OK) rc = match_mixed_impl(mx, d_bytes, d_off, n, seg_first, d_res, device, nullptr, total);
     if (rc == MFA_OK) {
         e = hipDeviceSynchronize();
         if (e == hipSuccess) e = hipMemcpy(results, d_res, n, hipMemcpyDeviceToHost);

@@ -17,7 +17,8 @@ ERR_INVALID_ARG, ERR_BAD_BLOB, ERR_UNSUPPORTED, ERR_NO_DEVICE, ERR_HIP, ERR_NOME
 EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_image_prepare", "mfa_image_specialize", "mfa_match_batch",
            "mfa_match_batch_regions", "mfa_region_scan", "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_last_region_ms",
            "mfa_device_count", "mfa_last_hip_error", "mfa_strerror", "mfa_version",
-           "mfa_mixed_create", "mfa_mixed_destroy", "mfa_match_mixed", "mfa_match_mixed_host", "mfa_mixed_last_ms", "mfa_mixed_timing"]
+           "mfa_mixed_create", "mfa_mixed_destroy", "mfa_match_mixed", "mfa_match_mixed_sized", "mfa_match_mixed_host", "mfa_mixed_last_ms", "mfa_mixed_timing",
+           "mfa_mixed_last_launches"]
 
 REGION_WORDS, REGION_MAX, REGION_OVERFLOW, REGION_MIN_LEN = 16, 15, 0x100, 64
 
@@ -71,6 +72,8 @@ def lib():
         L.mfa_mixed_destroy.argtypes = [vp]
         L.mfa_mixed_destroy.restype = None
         L.mfa_match_mixed.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32, vp]
+        L.mfa_match_mixed_sized.argtypes = [vp, vp, vp, u64, u64, ctypes.POINTER(u64), vp, i32, vp]
+        L.mfa_mixed_last_launches.argtypes = [vp, i32] + [ctypes.POINTER(ctypes.c_uint32)] * 4
         L.mfa_match_mixed_host.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32]
         L.mfa_mixed_last_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.mfa_mixed_timing.argtypes = [vp, i32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
@@ -182,8 +185,9 @@ class Mixed:
         arr = (ctypes.c_void_p * len(self._images))(*[im._h for im in self._images])
         _check(lib().mfa_mixed_create(arr, len(self._images), ctypes.byref(self._h)), "mfa_mixed_create")
 
-    def match_tensors(self, d_bytes, d_offsets, seg_first, d_results=None, stream=None):
-        """seg_first: host sequence of len(images) + 1 string indices.  Asynchronous on `stream` (default: the current one)."""
+    def match_tensors(self, d_bytes, d_offsets, seg_first, d_results=None, stream=None, total_bytes=0):
+        """seg_first: host sequence of len(images) + 1 string indices.  Asynchronous on `stream` (default: the current one).
+        total_bytes: the batch's size in bytes if the caller knows it (mfa_match_mixed_sized: nothing is read back)."""
         import torch
         n = d_offsets.numel() - 1
         dev = d_offsets.device.index or 0
@@ -191,9 +195,19 @@ class Mixed:
             d_results = torch.empty(max(n, 1), dtype=torch.uint8, device=d_offsets.device)
         s = stream if stream is not None else torch.cuda.current_stream(d_offsets.device)
         sf = (ctypes.c_uint64 * len(seg_first))(*[int(x) for x in seg_first])
-        _check(lib().mfa_match_mixed(self._h, d_bytes.data_ptr(), d_offsets.data_ptr(), n, sf, d_results.data_ptr(), dev,
-                                     ctypes.c_void_p(s.cuda_stream)), "mfa_match_mixed")
+        if total_bytes:
+            _check(lib().mfa_match_mixed_sized(self._h, d_bytes.data_ptr(), d_offsets.data_ptr(), n, int(total_bytes), sf, d_results.data_ptr(), dev,
+                                               ctypes.c_void_p(s.cuda_stream)), "mfa_match_mixed_sized")
+        else:
+            _check(lib().mfa_match_mixed(self._h, d_bytes.data_ptr(), d_offsets.data_ptr(), n, sf, d_results.data_ptr(), dev,
+                                         ctypes.c_void_p(s.cuda_stream)), "mfa_match_mixed")
         return d_results[:n]
+
+    def last_launches(self, device=0):
+        """what the last call launched: {"region_launches", "walk_launches", "groups", "gated"}"""
+        v = [ctypes.c_uint32() for _ in range(4)]
+        _check(lib().mfa_mixed_last_launches(self._h, device, *[ctypes.byref(x) for x in v]), "mfa_mixed_last_launches")
+        return {"region_launches": v[0].value, "walk_launches": v[1].value, "groups": v[2].value, "gated": bool(v[3].value)}
 
     def last_ms(self, device=0, back=0):
         """(region launches, first region launch to last walk) of the call `back` calls ago (0 = the last one), in ms"""

@@ -59,7 +59,7 @@ def gather_results(local_results, counts, dist, rank, world, dst=0, comm_device=
         bm = bm.to(comm_device)
     if bm.numel() < max_bytes:                      # gather needs equal sizes
         bm = torch.cat([bm, bm.new_zeros(max_bytes - bm.numel())])
-    if world == 1:
+    if world == 1 and dist is None:
         return unpack_bitmap(bm, int(counts[0]))
     bufs = [torch.empty_like(bm) for _ in range(world)] if rank == dst else None
     dist.gather(bm, bufs, dst=dst)

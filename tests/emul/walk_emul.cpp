@@ -133,7 +133,7 @@ int main(int argc, char** argv) {
         table.resize(n * MFA_REGION_WORDS);
         for (uint64_t k = 0; k < n; k++) region_row(bytes.data() + off[k], (uint32_t)(off[k + 1] - off[k]), &table[k * MFA_REGION_WORDS]);
     }
-    Batch b{bytes.data(), off.data(), n, res.data(), accel ? table.data() : nullptr, (uint32_t)(accel != 0), 1u, (uint32_t)seg_table.size(), seg_first.data(), seg_table.data()};
+    Batch b{bytes.data(), off.data(), n, res.data(), accel ? table.data() : nullptr, (uint32_t)(accel != 0), 1u, (uint32_t)seg_table.size(), seg_first.data(), seg_table.data(), 0u};
     WaveStats ws;
     if (n) {
 #define GO(KK) do { if (rev) run<KK, true>(b, T, C, CM, &ws); else run<KK, false>(b, T, C, CM, &ws); } while (0)

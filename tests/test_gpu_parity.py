@@ -745,3 +745,42 @@ def test_long_strings_every_image(name, monkeypatch):
         got = gpu_match(capi.Image(blob), strings)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, "%s %s: %d mismatches, first at string %d (len %d) want %d" % (name, engine, bad.size, bad[0], len(strings[bad[0]]), want[bad[0]])
+
+
+def test_config3_noise_strings_both_engines_and_mixed(monkeypatch):
+    """BASELINE configs[2]'s fourth kind of string: example 1 on 64 KiB strings of i.i.d. bytes
+    {a: 0.99, b: 0.01}, seed 0x5EED0003 -- hundreds of medium runs per string, more periodic stretches than a region-table row holds --
+    through both walk engines and through mfa_match_mixed, against the CPU restatement (mfa.cpp:177-191: every cell read compares a
+    run of a's with the run at the scan position).  A few strings with 0, 1 and 2 foreign bytes are mixed in so that both answers occur."""
+    import torch
+    n, length = 288, 65536
+    rng = np.random.Generator(np.random.Philox(0x5EED0003))
+    rows = np.where(rng.random((n, length)) < 0.01, ord("b"), ord("a")).astype(np.uint8)
+    rows[256:264] = ord("a")                                        # a^L: accepted
+    rows[264:272] = ord("a"); rows[264:272, -1] = ord("b")          # a^(L-1) b
+    rows[272:288] = ord("a")
+    for k in range(272, 288):
+        rows[k, rng.integers(0, length, size=2)] = ord("b")
+    strings = [r.tobytes() for r in rows]
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex1_plain"))
+    want = np.asarray(oracle_lib.OracleImage(blob).match(strings))
+    assert want[256:264].all() and not want[:256].any()
+    for engine in ("table", "specialised"):
+        use_engine(monkeypatch, engine)
+        img = capi.Image(blob)
+        got = gpu_match(img, strings)
+        assert np.array_equal(got, want), (engine, np.nonzero(got != want)[0][:5])
+        data, off = oracle_lib.pack(strings)
+        d_bytes = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+        d_bytes[:len(data)] = torch.from_numpy(data.copy())
+        d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+        mx = capi.Mixed([img])
+        for cuts in ("", "0.25,0.5"):
+            monkeypatch.setenv("MFA_MIXED_CUTS", cuts)
+            res = mx.match_tensors(d_bytes, d_off, [0, n]).clone()
+            torch.cuda.synchronize()
+            assert np.array_equal(res.cpu().numpy(), want), (engine, "mixed", cuts)
+        monkeypatch.delenv("MFA_MIXED_CUTS")
+        tab = capi.region_scan(d_bytes, d_off)
+        assert int(((tab[:256, 0] & capi.REGION_OVERFLOW) != 0).sum().item()) > 200      # the noise strings overflow their table rows
+        mx.close(); img.close()

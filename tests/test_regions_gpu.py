@@ -384,3 +384,86 @@ def test_bench_two_ranks_rehearsal(scaling):
     else:
         assert d["strings_by_rank"] == [30000, 30000]
 
+
+
+def test_bench_single_rank_rccl():
+    """RCCL executed once before an 8-GPU run does: bench.py as ONE rank that still goes through torch.distributed with the
+    `nccl` backend (MFA_BENCH_FORCE_DIST=1): communicator initialised on the device, all_gather / gather / all_reduce / barrier on
+    device tensors, the gathered bitmap compared with the local results by bench.py itself.  Two `nccl` ranks cannot share the one
+    GPU of this box: this is what a 1-GPU lease can prove of sharding.gather_results and bench.py's N > 1 branch."""
+    import json
+    import subprocess
+    import sys
+    root = oracle_lib.ROOT
+    env = dict(os.environ)
+    env.update({"MFA_BENCH_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1"})
+    env.pop("MASTER_PORT", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--strings-per-example", "3000", "--steps", "2", "--warmup", "1",
+                        "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["ranks_seen"] == 1 and d["backend"] == "nccl"
+    assert d["strings_by_rank"] == [30000] and d["bytes_by_rank"][0] > 0
+    assert "nccl" in d["config"]["exchange"] and d["parity_sample"]["mismatches"] == 0
+    assert "shard needs about" in p.stderr                        # the HBM preflight of multi-rank runs
+
+
+def test_gated_walks_see_fresh_tables(monkeypatch):
+    """The gate of mfa_match_mixed (ONE region launch, the walks of a group released by a counter the region kernel raises; walk_launch.hip,
+    regions.hip: gate_signal): the walk kernels start while the region kernel is still running and read table rows that other CUs -- other
+    XCDs -- have just written.  Two batches of the SAME shape and DIFFERENT content go through one mixed object in turn (one table buffer,
+    rewritten by every call): a walk that read a stale row -- the other batch's regions -- would walk over bytes that do not repeat and
+    answer wrongly.  Every call is compared with the ungated schedule (events behind per-group region launches) and a sample with the oracle."""
+    import torch
+    from mfa_amd import corpus
+    dev = torch.device("cuda", 0)
+    layout = [2, 5, 3, 8, 9, 10, 6, 4, 1, 7]
+    n_per = 9000
+    blobs = [image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex)) for ex in layout]
+    images = [capi.Image(b) for b in blobs]
+
+    def batch(variant):
+        parts_b, parts_o, seg, pos_b, samples = [], [], [0], 0, []
+        for ex in layout:
+            sizes = corpus.pump_sizes(n_per, 0x5EED0100 + ex, 200, 9000)          # the same lengths in both variants ...
+            ws = ((np.arange(n_per) + variant) % 2) == 0                            # ... but who has the suffix alternates: other answers
+            if variant:                                                            # ... and other strings: the pump sizes of the neighbours
+                sizes = np.roll(sizes, 1)
+            b, o = corpus.device_batch(ex, sizes, ws, dev)
+            nb = int(o[-1].item())
+            parts_b.append(b[:nb]); parts_o.append(o[:-1] + pos_b); pos_b += nb; seg.append(seg[-1] + n_per)
+            short = [k for k in range(n_per) if sizes[k] <= 1500][:25]
+            samples.append((short, corpus.host_strings(ex, sizes[short], ws[short])))
+        return (torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=dev)]),
+                torch.cat(parts_o + [torch.tensor([pos_b], dtype=torch.int64, device=dev)]), seg, samples, pos_b)
+
+    A, B = batch(0), batch(1)
+    monkeypatch.setenv("MFA_WALK", "table")
+    monkeypatch.setenv("MFA_MIXED_CUTS", "0.15,0.3,0.45,0.6,0.75,0.87,0.95")
+    mx = capi.Mixed(images)
+    ref = {}
+    monkeypatch.setenv("MFA_MIXED_GATE", "0")
+    for tag, (bts, off, seg, samples, total) in (("A", A), ("B", B)):
+        ref[tag] = mx.match_tensors(bts, off, seg).clone()
+        torch.cuda.synchronize()
+        assert not mx.last_launches()["gated"] and mx.last_launches()["region_launches"] == 8
+        for k, (short, strings) in enumerate(samples):
+            want = oracle_lib.OracleImage(blobs[k]).match(strings)
+            assert np.array_equal(ref[tag][seg[k]:seg[k + 1]][short].cpu().numpy(), want), (tag, layout[k])
+    assert not torch.equal(ref["A"], ref["B"])
+    monkeypatch.setenv("MFA_MIXED_GATE", "1")
+    res = torch.empty_like(ref["A"])
+    for r in range(40):
+        tag, (bts, off, seg, samples, total) = (("A", A), ("B", B))[r % 2]
+        res.fill_(7)
+        mx.match_tensors(bts, off, seg, res, total_bytes=total)
+        torch.cuda.synchronize()
+        la = mx.last_launches()
+        assert la["gated"] and la["region_launches"] == 1 and la["groups"] == 8
+        bad = torch.nonzero(res != ref[tag]).flatten()
+        assert bad.numel() == 0, "round %d (%s): %d answers differ from the ungated schedule, first at string %d" % (r, tag, bad.numel(), int(bad[0]))
+    # the tables themselves: the gated launch writes what per-group launches write
+    monkeypatch.setenv("MFA_MIXED_GATE", "0")
+    mx.close()

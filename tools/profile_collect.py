@@ -45,8 +45,11 @@ write_r, write_w, n_w = pmc_sum("WRITE_SIZE")
 fetch, write = fetch_r + fetch_w, write_r + write_w
 alg = bench["roofline"]["algorithmic_bytes_per_step"]
 cfg = bench["config"]
+sys.path.insert(0, os.path.join(ROOT, "re2-modification_amd"))
+from mfa_amd import srchash
 traffic = {
-    "round": 3, "tag": tag,
+    "round": int(tag[1:3]) if tag[1:3].isdigit() else 0, "tag": tag,
+    "csrc_sha16": srchash.kernel_source_hash(),      # bench.py quotes these counters only while the kernel sources still hash to this
     "workload": {"strings_per_example": cfg.get("strings_per_example", 125000), "min_len": cfg.get("min_len", 1024),
                  "max_len": cfg.get("max_len", 65536), "n_gpus": bench["n_gpus"]},
     "how": "two separate rocprofv3 --pmc passes over `python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-secondary` (FETCH_SIZE, then "
