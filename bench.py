@@ -502,7 +502,20 @@ def secondary_no_regions(device, capi, corpus, n_strings=262144, length=4096):
                       "kernel": "region_scan_kernel + " + KERNEL_NAMES.get(img.info()["last_kernel"], "?"), "region_ms": tr, "walk_ms": t, "GB/s": nb / ((t + tr) * 1e-3) / 1e9,
                       "char_steps_per_s": nb / ((t + tr) * 1e-3), "accepted": int(res.sum().item()),
                       "parity_oracle_sample": _oracle_sample(blob, short, got)})
-        del d_b, d_o, res
+        # the same batch through mfa_match_mixed (the table engine: strings without periodic stretches are handed to walk_lean_kernel -- the
+        # plain step only, twice the waves per SIMD -- whatever the automaton, no generated kernel needed)
+        mx = capi.Mixed([img])
+        res_m = torch.empty(n_strings, dtype=torch.uint8, device=device)
+        spans = []
+        for _ in range(3):
+            mx.match_tensors(d_b, d_o, [0, n_strings], res_m, total_bytes=nb); torch.cuda.synchronize()
+            spans.append(mx.last_ms(device.index or 0)[1])
+        span = float(np.mean(spans[1:]))
+        lines.append({"workload": "non-periodic text, example %d, the same batch through mfa_match_mixed" % ex,
+                      "kernel": "mfa_match_mixed: region_scan_kernel + walk_kernel (table-driven) + walk_lean_kernel", "span_ms": span, "GB/s": nb / (span * 1e-3) / 1e9,
+                      "char_steps_per_s": nb / (span * 1e-3), "results_equal": bool(torch.equal(res, res_m)), "launches": mx.last_launches(device.index or 0)})
+        mx.close()
+        del d_b, d_o, res, res_m
     # example 1, attack strings, no table: every step is executed
     img = capi.Image(load_blob("ex1_plain"))
     n1 = 262144

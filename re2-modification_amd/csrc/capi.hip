@@ -21,6 +21,7 @@ void set_last_hip_error(int e) { g_last_hip_error = e; }
 
 static void ctx_free(LaunchCtx& cx) {
     if (cx.d_counter) (void)hipFree(cx.d_counter);
+    lean_hint_free(cx.lean);
     if (cx.d_scratch) (void)hipFree(cx.d_scratch);
     if (cx.d_regions) (void)hipFree(cx.d_regions);
     for (void* ev : {cx.ev_start, cx.ev_stop, cx.ev_r0, cx.ev_r1, cx.ev_done})
@@ -252,7 +253,7 @@ static int match_impl(mfa_image_t* img, const uint8_t* d_bytes, const uint64_t* 
         if (n > 0xffffffffull) return MFA_ERR_INVALID_ARG;
         HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_start, (hipStream_t)stream));
         rc = launch_walk(p, ds->d_walk, ds->n_cus, d_bytes, d_offsets, n, d_results, d_table, 1u, sf, stb, &cx->d_scratch, &cx->scratch_bytes,
-                         cx->d_counter, stream);
+                         cx->d_counter, stream, 0u, &cx->lean);
         HIP_TRY(hipEventRecord((hipEvent_t)cx->ev_stop, (hipStream_t)stream));
     } else if (jit) {
         img->last_kernel = MFA_KERNEL_SPECIALISED;

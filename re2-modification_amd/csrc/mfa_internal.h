@@ -43,7 +43,17 @@ int tabulate_nfa(HostImage& img);                                    // fills th
 // pool of its (image, device); a context is reused by a later launch on the SAME stream (stream order makes
 // that safe) or once its `done` event has completed, so launches of one image that overlap on different
 // streams or from different host threads never share a counter, a scratch buffer or an event.
+// Whether the lean kernel behind a table walk (walk.hip: strings without periodic stretches) has had anything to do lately: the kernel
+// reports the length of its queue (+ 1) to a word of pinned host memory, and a launch whose slot saw two empty queues in a row leaves
+// the lean kernel and the queue out (one launch less on the stream) -- except every eighth time, to notice when the input changes.
+struct LeanHint {
+    uint32_t* h_seen = nullptr;      // pinned, device-visible; 0 = nothing reported yet
+    uint32_t quiet = 0, launches = 0;
+};
+void lean_hint_free(LeanHint& h);
+
 struct LaunchCtx {
+    LeanHint lean;
     unsigned long long* d_counter = nullptr;   // next-string ticket (+ MFA_STATS words)
     uint32_t*           d_scratch = nullptr;   // slot arrays / probe images that do not fit LDS
     size_t              scratch_bytes = 0;
@@ -125,7 +135,7 @@ void device_release(DeviceState& ds);
 struct WalkPlanInput { uint32_t K, max_live; bool reversed; uint32_t table_words; };
 int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                 uint8_t* d_results, const uint64_t* d_regions, uint32_t n_seg, const uint32_t* seg_first, const uint32_t* seg_table,
-                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate = 0);
+                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate = 0, LeanHint* lean = nullptr);
 int  walk_mode();          // MFA_WALK: 0 auto (default), 1 table, 2 jit
 void set_last_hip_error(int e);
 

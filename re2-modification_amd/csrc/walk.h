@@ -26,6 +26,9 @@ struct WalkArgs {                     // kernel parameters; every pointer is a d
     uint32_t n_seg, C, CX, accel, refill;
     uint32_t images_global;           // the two probe images of a lane live in global memory (less LDS per wave: more waves per CU)
     uint32_t gate;                    // 0, or 0x1000 | stamp: the region table is being written while the kernel runs, rows carry this stamp (regions.hip: GATE)
+    uint32_t* lean_queue;             // strings without a periodic stretch are handed to walk_lean_kernel through this queue (nullptr: all are walked here);
+                                      //   its length is counter[1] (as 32 bits), the lean kernel's ticket counter counter[2]
+    uint32_t* lean_seen;              // pinned host word (or nullptr): the lean kernel stores the queue's length + 1 there (mfa_internal.h: LeanHint)
     uint32_t seg_first[WALK_MAX_SEG + 1];    // segment s = strings seg_first[s] .. seg_first[s+1]-1 of this launch ...
     uint32_t seg_table[WALK_MAX_SEG];        // ... walks the automaton whose table block starts at this word of `tables`
 };
@@ -33,6 +36,8 @@ struct WalkArgs {                     // kernel parameters; every pointer is a d
 struct WalkLaunch {
     WalkArgs args;
     unsigned grid;                    // workgroups of 256 threads
+    unsigned lean_grid;               // ... of the lean kernel that follows (0: none)
+    uint32_t lean_C;                  // its list capacity in LDS
     bool     reversed;
     bool     tables_global;           // the tables do not fit LDS: the kernel reads them from global memory (shared_words = 0)
 };

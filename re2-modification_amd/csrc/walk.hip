@@ -74,7 +74,8 @@ walk_kernel(WalkArgs a) {
     st.gsb = g; g += XI * W * 64u;
     st.gsa = g; g += XI * DW * 64u;
     st.gq = g;
-    Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.refill, a.n_seg, a.seg_first, a.seg_table, a.gate};
+    Batch b{a.bytes, a.offsets, a.n, a.results, a.regions, a.accel, a.refill, a.n_seg, a.seg_first, a.seg_table, a.gate,
+            a.lean_queue, reinterpret_cast<uint32_t*>(a.counter + 1)};
     TicketFeeder feed{a.counter, a.n, gwave * 64u};
 #if WALK_STATS
     // development build: per-lane counts and per-wave cycle counts, added up in a.counter[8 ..]
@@ -93,6 +94,53 @@ walk_kernel(WalkArgs a) {
     if (TG) walk_wave<K, REV, TicketFeeder, TablePtrG>(b, a.tables, st, rtc, feed, nullptr);
     else walk_wave<K, REV, TicketFeeder, TablePtr>(b, (TablePtr)smem, st, rtc, feed, nullptr);
 #endif
+}
+
+// ---- the lean walk: strings without periodic stretches, from the queue the kernel above fills (walk_core.h: walk_wave_lean) -----------------
+struct QueueFeeder {
+    const uint32_t* queue;
+    uint32_t count;
+    unsigned long long* counter;
+    __device__ __forceinline__ bool take(bool want, uint64_t& sid) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const unsigned long long wb = __ballot(want);
+        const int leader = __builtin_ctzll(wb);
+        unsigned long long first = 0;
+        if (lane == (uint32_t)leader) first = atomicAdd(counter, (unsigned long long)__builtin_popcountll(wb));
+        const uint32_t at = (uint32_t)__shfl((uint32_t)first, leader) + (uint32_t)__builtin_popcountll(wb & ((1ull << lane) - 1ull));
+        const bool got = want && at < count;
+        sid = got ? queue[at] : 0u;
+        return got;
+    }
+};
+
+// LDS of a workgroup: [tables] then per wave the two lists (values only)
+template <int K, bool REV, bool TG, int NKEYS>
+__global__ void __launch_bounds__(256, 4)
+walk_lean_kernel(WalkArgs a) {
+    extern __shared__ uint32_t smem[];
+    const uint32_t count = *reinterpret_cast<const uint32_t*>(a.counter + 1);      // final: the kernel that fills the queue has ended
+    if (a.lean_seen != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.lean_seen, count + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (count == 0u) return;
+    if (!TG) {
+        for (uint32_t k = threadIdx.x; k < a.table_words; k += blockDim.x) smem[k] = a.tables[k];
+        __syncthreads();
+    }
+    constexpr uint32_t W = Lay<K>::W;
+    const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    Store st;
+    st.C = a.C; st.CX = a.CX; st.CI = 0u;
+    st.lv = (WALK_LDS uint32_t*)smem + a.shared_words + wave_u * (2u * a.C * W * 64u);
+    st.ld = nullptr; st.sb = nullptr; st.sa = nullptr;
+    const uint64_t gwave = (uint64_t)blockIdx.x * 4u + wave_u;
+    uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * 2u * W + CMP_CACHE * 4u * 64u);
+    st.gv = g; g += 2u * a.CX * W * 64u;
+    st.gd = nullptr; st.gsb = nullptr; st.gsa = nullptr;
+    st.gq = g;
+    Batch b{a.bytes, a.offsets, a.n, a.results, nullptr, 0u, a.refill, a.n_seg, a.seg_first, a.seg_table, 0u, nullptr, nullptr};
+    QueueFeeder feed{a.lean_queue, count, a.counter + 2};
+    if (TG) walk_wave_lean<K, REV, QueueFeeder, TablePtrG>(b, a.tables, st, feed);
+    else walk_wave_lean<K, REV, QueueFeeder, TablePtr>(b, (TablePtr)smem, st, feed);
 }
 
 #define WALK_CAT2(a, b) a##b
@@ -124,6 +172,24 @@ int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
     else { if (L.reversed) WALK_GO(true, false); else WALK_GO(false, false); }
 #undef WALK_GO
     if (e == hipSuccess) e = hipGetLastError();
+#if !WALK_STATS
+    if (e == hipSuccess && L.lean_grid != 0u && a.lean_queue != nullptr) {
+        // behind it, on the same stream: the strings it has handed on (the kernel ends at once when there are none)
+        WalkArgs al = a;
+        al.C = L.lean_C;
+        al.CX = a.CX + a.C > al.C ? a.CX + a.C - al.C : 1u;
+        const size_t lds_l = ((size_t)a.shared_words + 4u * (size_t)al.C * 64u * 2u * Lay<WALK_K>::W) * 4u;
+#define WALK_GO_LEAN(REVV, TGV)                                                                                                              \
+    do {                                                                                                                                     \
+        e = hipFuncSetAttribute((const void*)walk_lean_kernel<WALK_K, REVV, TGV, WALK_KEYS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l); \
+        if (e == hipSuccess) hipLaunchKernelGGL((walk_lean_kernel<WALK_K, REVV, TGV, WALK_KEYS>), dim3(L.lean_grid), dim3(256), lds_l, s, al);          \
+    } while (0)
+        if (L.tables_global) { if (L.reversed) WALK_GO_LEAN(true, true); else WALK_GO_LEAN(false, true); }
+        else { if (L.reversed) WALK_GO_LEAN(true, false); else WALK_GO_LEAN(false, false); }
+#undef WALK_GO_LEAN
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+#endif
     if (e != hipSuccess) { set_last_hip_error((int)e); return MFA_ERR_HIP; }
     return MFA_OK;
 }

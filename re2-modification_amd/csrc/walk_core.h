@@ -50,6 +50,9 @@
 #ifndef WALK_PROBE_PERIODS
 #define WALK_PROBE_PERIODS 5u
 #endif
+#ifndef WALK_LEAN_MIN_LEN
+#define WALK_LEAN_MIN_LEN 256u      /* shorter strings are not worth a second look */
+#endif
 #ifndef WALK_TAIL
 #define WALK_TAIL 8u         /* a probe with period p starts only where 4 p + WALK_TAIL positions of the region are left */
 #endif
@@ -75,6 +78,8 @@ WALK_DEV uint32_t wv_lane() { return 0u; }
 WALK_DEV uint64_t wv_shfl64(uint64_t v, int) { return v; }
 WALK_DEV uint64_t wv_load_fresh(const uint64_t* p) { return *p; }
 WALK_DEV void wv_nap() {}
+WALK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) { const uint32_t o = *p; *p = o + v; return o; }
+WALK_DEV uint32_t wv_bcast32(uint32_t v, int) { return v; }
 // the wave-wide scans of device_common.h assume 64 lanes: scalar restatements for the one-lane wave
 template <bool REV>
 inline uint32_t coop_run_end_x(const uint8_t* bytes, uint64_t base, uint32_t len, uint32_t i0, uint32_t) {
@@ -96,6 +101,8 @@ WALK_DEV uint32_t wv_lane() { return threadIdx.x & 63u; }
 // a load that does not take this CU's L1 copy for an answer (agent scope: `sc1`), and a pause between two polls
 WALK_DEV uint64_t wv_load_fresh(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 WALK_DEV void wv_nap() { __builtin_amdgcn_s_sleep(16); }
+WALK_DEV uint32_t wv_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+WALK_DEV uint32_t wv_bcast32(uint32_t v, int L) { return (uint32_t)__shfl((int)v, L); }
 WALK_DEV uint64_t wv_shfl64(uint64_t v, int L) { return ((uint64_t)__shfl((uint32_t)(v >> 32), L) << 32) | __shfl((uint32_t)v, L); }
 // Out of line on purpose: a scan is rare (a run the region table does not hold, a long comparison outside known regions), sits in
 // the innermost loop of the step, and inlined it raised the kernel's register count by 25 for every wave, scanning or not.
@@ -990,6 +997,8 @@ struct Batch {
     const uint32_t* seg_first;   //   start at word seg_table[s] of the table block (n_seg + 1 / n_seg entries, 32-bit string indices)
     const uint32_t* seg_table;
     uint32_t gate;               // WIn::gate
+    uint32_t* lean_queue;        // strings WITHOUT a periodic stretch (an empty table row) of at least WALK_LEAN_MIN_LEN bytes are not walked by this kernel:
+    uint32_t* lean_count;        //   their numbers go to this queue (nullptr: none), which walk_wave_lean works off afterwards
 };
 
 struct WaveStats {
@@ -1080,7 +1089,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
     for (;;) {
         unsigned long long tm = stats ? wv_clock() : 0ull;
 #define WALK_LAP(field) do { if (stats) { const unsigned long long now_ = wv_clock(); stats->field += now_ - tm; tm = now_; } } while (0)
-        {   // hand strings to idle lanes
+        for (;;) {   // hand strings to idle lanes (again, if every string this trip handed out went to the lean queue)
             // Idle lanes take new strings together: a string's start is three dependent trips to memory (ticket, offsets, first
             // bytes) that the whole wave waits for, so it is paid once per `refill` lanes, not once per lane that runs out
             const bool want = !active && !exhausted;
@@ -1097,7 +1106,17 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                         const uint64_t sid = s;
                         const uint64_t o0 = b.offsets[sid], o1 = b.offsets[sid + 1];
                         if (o1 - o0 > MFA_DEV_MAX_LEN) b.results[sid] = 2;
-                        else {
+                        else if (b.lean_queue != nullptr && b.regions != nullptr && (rta.x & 0x1ffu) == 0u && o1 - o0 >= WALK_LEAN_MIN_LEN) {
+                            // A string whose row is empty has no periodic stretch: every one of its steps will be executed, nothing of the probe
+                            // machinery is of use to it.  Such strings go to a queue and are walked afterwards by a kernel that has the plain step
+                            // only -- fewer registers, less LDS, twice the waves per SIMD (walk_wave_lean).  (The lanes in this branch.)
+                            const unsigned long long lb = __ballot(true);
+                            const int leader = __builtin_ctzll(lb);
+                            uint32_t at = 0;
+                            if (wv_lane() == (uint32_t)leader) at = wv_atomic_add(b.lean_count, (uint32_t)__builtin_popcountll(lb));
+                            at = wv_bcast32(at, leader);
+                            b.lean_queue[at + (uint32_t)__builtin_popcountll(lb & ((1ull << wv_lane()) - 1ull))] = (uint32_t)sid;
+                        } else {
                             len = (uint32_t)(o1 - o0);
                             w_reset(in, o0, len, (uint32_t)sid);
                             w_rt_attach(in, warm, rta, rtb);
@@ -1119,6 +1138,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                     }
                 }
             }
+            if (__any(active) || __all(exhausted)) break;
         }
         if (!__any(active)) break;
         if (stats) stats->iters++;
@@ -1302,6 +1322,72 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
     }
 #undef WALK_LAP
     if (stats) stats->t_total += wv_clock() - tm_begin;
+}
+
+// The walk of strings without periodic stretches (the queue the walk above fills): the plain step and nothing else -- no probes, no
+// images, no directions, no shape history.  Same lists, same step function, same answers; about 60 registers fewer, a third of the LDS.
+template <int K, bool REV, class Feeder, class TP>
+WALK_DEV void walk_wave_lean(const Batch& b, TP T, const Store& st, Feeder& feed) {
+    WIn in;
+    in.bytes = b.bytes; in.total16 = (b.offsets[b.n] + 15u) & ~(uint64_t)15; in.regions = nullptr; in.rtc = nullptr; in.gate = 0u;
+    w_reset(in, 0, 0, 0);
+    in.w0 = in.w1 = in.w2 = in.w3 = 0;
+    bool active = false, exhausted = false, accept = false;
+    uint32_t i = 0, len = 0, cur = 0, n_cur = 0;
+    Aut au;
+    aut_load(au, T, 0u);
+    for (;;) {
+        {
+            const bool want = !active && !exhausted;
+            const unsigned long long wantb = __ballot(want);
+            if (wantb && ((uint32_t)__builtin_popcountll(wantb) >= b.refill || !__any(active))) {
+                uint64_t s = 0;
+                const bool got = feed.take(want, s);
+                if (want) {
+                    if (!got) exhausted = true;
+                    else {
+                        const uint64_t o0 = b.offsets[s], o1 = b.offsets[s + 1];
+                        len = (uint32_t)(o1 - o0);
+                        w_reset(in, o0, len, (uint32_t)s);
+                        uint32_t seg = 0;
+                        for (uint32_t k = 1; k < b.n_seg; k++)
+                            if (s >= b.seg_first[k]) seg = k;
+                        aut_load(au, T, b.n_seg ? b.seg_table[seg] : 0u);
+                        i = 0; accept = false; active = true;
+                        n_cur = 1;                                    // the list: (pos 0, start, no cells)  mfa.cpp:217-219
+                        Ent<uint32_t, K> e0;
+                        e0.P = 0u; e0.vid = aut_start(T, au);
+#pragma unroll
+                        for (int c = 0; c < K; c++) { e0.S[c] = 0u; e0.L[c] = 0u; e0.F[c] = 0u; }
+                        bool f2 = true;
+                        store_entry<uint32_t, K>(st, cur, 0u, e0, 0u, f2);
+                    }
+                }
+            }
+        }
+        if (!__any(active)) break;
+        const bool final_pass = (i == len);
+        uint32_t ch = 0x100u;
+        if (active && !final_pass) ch = w_stream_byte<REV>(in, i);
+        uint32_t n_next = 0, shape = 0;
+        const bool accept_before = accept;
+        in.cq_n = 0u;
+        for (;;) {                                                   // (again after the wave has answered what the step asked for)
+            n_next = 0; accept = accept_before;
+            tb_t TB = tb_init();
+            bool f2 = true;
+            walk_step<uint32_t, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB, shape);
+            if (!__any(active && in.rq != 0u)) break;
+            answer_requests<REV>(st, in, active);
+        }
+        cur ^= 1u;
+        if (active) {
+            n_cur = n_next;
+            const bool done = accept || final_pass || n_next == 0u;      // mfa.cpp:224-225, 227-235
+            i++;
+            if (done) { b.results[in.sid] = accept ? 1 : 0; active = false; n_cur = 0u; }
+        }
+    }
 }
 
 }  // namespace mfa_walk

@@ -43,7 +43,7 @@ static size_t wave_words(uint32_t K, uint32_t C, bool ig) {
 // longest possible list if that leaves room for two workgroups per CU, else what does (longer lists spill to `d_spill`).
 int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                 uint8_t* d_results, const uint64_t* d_regions, uint32_t n_seg, const uint32_t* seg_first, const uint32_t* seg_table,
-                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate) {
+                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate, LeanHint* lean) {
     if (n == 0) return MFA_OK;
     if (n_seg == 0 || n_seg > WALK_MAX_SEG || n > 0xffffffffull) return MFA_ERR_INVALID_ARG;
     WalkLaunch L;
@@ -95,12 +95,45 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     if (grid * 4u * per_wave > budget) return MFA_ERR_NOMEM;
     L.grid = (unsigned)grid;
     L.reversed = p.reversed;
-    const size_t need = (size_t)grid * 4u * per_wave;
-    int rc = ctx_reserve((void**)d_spill, spill_bytes, need);
+    // the lean kernel behind it (strings without periodic stretches: walk.hip): the plain step only, lists of the same capacity, four
+    // workgroups per CU where the LDS allows; its waves' spill areas and the queue of string numbers share the buffer with this launch's
+    L.lean_grid = 0; L.lean_C = a.C;
+    size_t lean_bytes = 0, queue_at = 0;
+    bool want_lean = d_regions != nullptr && a.accel != 0u && env_int("MFA_WALK_LEAN", 1) != 0;
+    if (want_lean && lean != nullptr) {
+        if (lean->h_seen == nullptr && hipHostMalloc((void**)&lean->h_seen, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) *lean->h_seen = 0u;
+        if (lean->h_seen == nullptr) (void)hipGetLastError();
+        else {
+            const uint32_t seen = *(volatile uint32_t*)lean->h_seen;      // what the last lean kernel of this slot that has ended found (+ 1)
+            lean->quiet = seen == 1u ? lean->quiet + 1u : 0u;
+            if (seen != 1u) lean->quiet = 0u;
+            if (lean->quiet >= 2u && (lean->launches & 7u) != 0u && env_int("MFA_WALK_LEAN", 1) != 2) want_lean = false;      // (MFA_WALK_LEAN=2: always)
+            lean->launches++;
+            a.lean_seen = lean->h_seen;
+        }
+    }
+    if (want_lean) {
+        const size_t lean_wave_words = (size_t)a.C * 64u * 2u * W;
+        uint64_t lean_per_cu = lds_max / (a.shared_words + 4u * lean_wave_words);
+        if (lean_per_cu > 4) lean_per_cu = 4;
+        if (lean_per_cu >= 1) {
+            uint64_t lg = (uint64_t)(n_cus > 0 ? n_cus : 256) * lean_per_cu;
+            if (lg > want) lg = want;
+            const size_t lean_per_wave = ((size_t)(a.CX + a.C) * 64u * 2u * W + 4u * 4u * 64u) * sizeof(uint32_t);
+            while (lg > 1 && lg * 4u * lean_per_wave > budget) lg = (lg + 1) / 2;
+            L.lean_grid = (unsigned)lg;
+            lean_bytes = (size_t)lg * 4u * lean_per_wave;
+        }
+    }
+    const size_t need = std::max((size_t)grid * 4u * per_wave, lean_bytes);
+    queue_at = (need + 255u) & ~(size_t)255u;
+    int rc = ctx_reserve((void**)d_spill, spill_bytes, queue_at + (L.lean_grid ? (size_t)n * sizeof(uint32_t) : 0));
     if (rc != MFA_OK) return rc;
     a.spill = *d_spill;
+    a.lean_queue = L.lean_grid ? reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(*d_spill) + queue_at) : nullptr;
     const bool stats = getenv("MFA_WALK_STATS") != nullptr && p.K == 1;
-    HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long) * (stats ? 32 : 1), (hipStream_t)stream));
+    if (stats) { a.lean_queue = nullptr; L.lean_grid = 0; }
+    HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long) * (stats ? 32 : 3), (hipStream_t)stream));      // ticket counter, queue length, the lean kernel's tickets
     if (stats) {
         rc = launch_walk_stats(L, stream);
         if (rc == MFA_OK) { (void)hipStreamSynchronize((hipStream_t)stream); walk_print_stats(d_counter, "walk"); }
@@ -113,6 +146,11 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
         case 7: return launch_walk_k7(L, stream); case 8: return launch_walk_k8(L, stream); case 9: return launch_walk_k9(L, stream);
     }
     return MFA_ERR_UNSUPPORTED;
+}
+
+void lean_hint_free(LeanHint& h) {
+    if (h.h_seen) (void)hipHostFree(h.h_seen);
+    h.h_seen = nullptr;
 }
 
 void walk_print_stats(unsigned long long* d_counter, const char* tag) {
@@ -159,6 +197,7 @@ struct mfa_mixed {
         uint64_t calls = 0;
         uint64_t* d_regions = nullptr; size_t region_bytes = 0;
         uint32_t* d_spill[MIX_MAX_LAUNCHES] = {nullptr}; size_t spill_bytes[MIX_MAX_LAUNCHES] = {0};
+        LeanHint lean[MIX_MAX_LAUNCHES];
         unsigned long long* d_counters = nullptr;
         int n_cus = 0;
         // the gate: ONE region launch per call; in front of a group's walk launches, on their stream, one wave that ends when the region
@@ -219,6 +258,7 @@ void mfa_mixed_destroy(mfa_mixed_t* mx) {
         if (d.d_tables) (void)hipFree(d.d_tables);
         if (d.d_regions) (void)hipFree(d.d_regions);
         for (uint32_t* p : d.d_spill) if (p) (void)hipFree(p);
+        for (LeanHint& h : d.lean) lean_hint_free(h);
         if (d.d_counters) (void)hipFree(d.d_counters);
         if (d.h_hdr) (void)hipHostFree(d.h_hdr);
         if (d.ev_clear) (void)hipEventDestroy(d.ev_clear);
@@ -479,7 +519,7 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
                 const WalkPlanInput pk{L.Kc, L.ml, mx->reversed, L.w1 - L.w0};
                 join.used[L.k] = true;
                 rc = launch_walk(pk, d->d_tables + L.w0, d->n_cus, d_bytes, d_offsets + L.a, L.b - L.a, d_results + L.a, d_table ? d_table + L.a * MFA_REGION_WORDS : nullptr,
-                                 L.s1 - L.s0, sf, stb, &d->d_spill[slot], &d->spill_bytes[slot], d->d_counters + 64 * slot, d->ws[L.k], gate ? (0x1000u | stamp) : 0u);
+                                 L.s1 - L.s0, sf, stb, &d->d_spill[slot], &d->spill_bytes[slot], d->d_counters + 64 * slot, d->ws[L.k], gate ? (0x1000u | stamp) : 0u, &d->lean[slot]);
                 if (rc != MFA_OK) return rc;
                 slot++;
             }

@@ -66,6 +66,15 @@ static void region_row(const uint8_t* s, uint32_t len, uint64_t* row) {
     for (size_t k = 0; k < keep.size(); k++) row[1 + k] = (uint64_t)keep[k].lo | ((uint64_t)keep[k].hi << 24) | ((uint64_t)keep[k].q << 48);
 }
 
+struct QueueSeqFeeder {                       // the lean walk's strings: the queue the first pass filled
+    const uint32_t* queue; uint32_t count, next = 0;
+    bool take(bool want, uint64_t& sid) {
+        if (!want || next >= count) return false;
+        sid = queue[next++];
+        return true;
+    }
+};
+
 struct SeqFeeder {
     uint64_t next = 0, n = 0;
     bool take(bool want, uint64_t& sid) {
@@ -86,6 +95,14 @@ static void run(const Batch& b, const std::vector<uint32_t>& T, uint32_t C, uint
     SeqFeeder feed;
     feed.n = b.n;
     walk_wave<K, REV, SeqFeeder>(b, T.data(), st, rtc, feed, ws);
+    if (b.lean_queue != nullptr && *b.lean_count != 0u) {      // the strings handed on: the plain step only (walk_core.h: walk_wave_lean)
+        Store sl = st;
+        sl.ld = nullptr; sl.sb = nullptr; sl.sa = nullptr; sl.gd = nullptr; sl.gsb = nullptr; sl.gsa = nullptr; sl.CI = 0;
+        QueueSeqFeeder qf{b.lean_queue, *b.lean_count};
+        Batch bl = b;
+        bl.regions = nullptr; bl.accel = 0; bl.lean_queue = nullptr; bl.lean_count = nullptr;
+        walk_wave_lean<K, REV, QueueSeqFeeder>(bl, T.data(), sl, qf);
+    }
 }
 
 int main(int argc, char** argv) {
@@ -133,7 +150,10 @@ int main(int argc, char** argv) {
         table.resize(n * MFA_REGION_WORDS);
         for (uint64_t k = 0; k < n; k++) region_row(bytes.data() + off[k], (uint32_t)(off[k + 1] - off[k]), &table[k * MFA_REGION_WORDS]);
     }
-    Batch b{bytes.data(), off.data(), n, res.data(), accel ? table.data() : nullptr, (uint32_t)(accel != 0), 1u, (uint32_t)seg_table.size(), seg_first.data(), seg_table.data(), 0u};
+    Batch b{bytes.data(), off.data(), n, res.data(), accel ? table.data() : nullptr, (uint32_t)(accel != 0), 1u, (uint32_t)seg_table.size(), seg_first.data(), seg_table.data(), 0u, nullptr, nullptr};
+    std::vector<uint32_t> lean_queue(n ? n : 1);
+    uint32_t lean_count = 0;
+    if (accel && !getenv("EMUL_NO_LEAN")) { b.lean_queue = lean_queue.data(); b.lean_count = &lean_count; }
     WaveStats ws;
     if (n) {
 #define GO(KK) do { if (rev) run<KK, true>(b, T, C, CM, &ws); else run<KK, false>(b, T, C, CM, &ws); } while (0)
@@ -141,6 +161,7 @@ int main(int argc, char** argv) {
                      case 6: GO(6); break; case 7: GO(7); break; case 8: GO(8); break; default: GO(9); break; }
     }
     for (uint64_t k = 0; k < n; k++) { putchar('0' + res[k]); putchar('\n'); }
+    fprintf(stderr, "emul: %u of the strings walked by the lean pass\n", lean_count);
     fprintf(stderr, "emul: %llu strings, steps %llu, dual %llu, probes %llu, hits %llu, skipped %llu, spill-steps %llu\n", (unsigned long long)n, ws.steps, ws.dual,
             ws.probes, ws.hits, ws.skipped, ws.spills);
     if (getenv("EMUL_HIST")) { fprintf(stderr, "events: entries %llu edge-evals %llu inserts %llu search-iters %llu c-items %llu\n", g_ev[0], g_ev[1], g_ev[2], g_ev[3], g_ev[6]); for (int k = 0; k < 80; k++) if (ws.hist[k]) fprintf(stderr, " n=%d:%llu", k, ws.hist[k]); fprintf(stderr, "\n"); }

@@ -784,3 +784,42 @@ def test_config3_noise_strings_both_engines_and_mixed(monkeypatch):
         tab = capi.region_scan(d_bytes, d_off)
         assert int(((tab[:256, 0] & capi.REGION_OVERFLOW) != 0).sum().item()) > 200      # the noise strings overflow their table rows
         mx.close(); img.close()
+
+
+@pytest.mark.parametrize("name", ["ex1_plain", "ex6_plain", "ex9_plain", "ex8_reverse", "ex2_bnf"])
+def test_lean_walk_of_text_without_stretches(name, monkeypatch):
+    """The table engine hands strings without periodic stretches (an empty region-table row, 256 bytes and more) to walk_lean_kernel through
+    a queue (walk.hip): a batch that mixes such text with attack strings and short strings, against the CPU restatement, with the lean
+    kernel and with MFA_WALK_LEAN=0, through the single-automaton call and through mfa_match_mixed."""
+    import random
+    import torch
+    from mfa_amd import corpus
+    rng = random.Random(3 + len(name))
+    strings = []
+    for _ in range(300):
+        strings.append(b"".join((b"a" * rng.randint(1, 20) + b"b") for _ in range(rng.randint(5, 400))))
+        strings.append(bytes(rng.choice(b"ab") for _ in range(rng.randint(200, 3000))))
+    ex = int("".join(c for c in name.split("_")[0] if c.isdigit()))
+    regex, pump, suffix, prefix = corpus.ALL_EXAMPLES[ex]
+    for n in (300, 2000, 9000):
+        strings.append((prefix + corpus.pumped_string(n, pump) + suffix).encode())
+        strings.append((prefix + corpus.pumped_string(n, pump)).encode())
+    strings += [b"", b"a", b"ab" * 100, b"b" * 255]
+    rng.shuffle(strings)
+    blob = image.blob_from_dump(oracle_lib.load_dump(name))
+    want = np.asarray(oracle_lib.OracleImage(blob).match(strings))
+    monkeypatch.setenv("MFA_WALK", "table")
+    for lean in ("1", "0"):
+        monkeypatch.setenv("MFA_WALK_LEAN", lean)
+        img = capi.Image(blob)
+        got = gpu_match(img, strings)
+        assert np.array_equal(got, want), (name, lean, np.nonzero(got != want)[0][:5])
+        data, off = oracle_lib.pack(strings)
+        d_bytes = torch.zeros(len(data) + 64, dtype=torch.uint8, device="cuda")
+        d_bytes[:len(data)] = torch.from_numpy(data.copy())
+        d_off = torch.from_numpy(off.astype(np.int64)).cuda()
+        mx = capi.Mixed([img])
+        res = mx.match_tensors(d_bytes, d_off, [0, len(strings)]).clone()
+        torch.cuda.synchronize()
+        assert np.array_equal(res.cpu().numpy(), want), (name, lean, "mixed")
+        mx.close(); img.close()

@@ -98,3 +98,30 @@ def test_mixed_segments(emul, tmp_path):
         args += [paths[k], seg[k]]
     got = run_emul(emul, args, strings)
     assert np.array_equal(got, np.array(want, dtype=np.uint8))
+
+
+def text_without_stretches(rng, n):
+    """strings that hold no periodic stretch of 64 bytes: short runs of a's cut by b's, and coin tosses"""
+    out = []
+    for _ in range(n):
+        out.append(b"".join((b"a" * rng.randint(1, 20) + b"b") for _ in range(rng.randint(5, 120))))
+        out.append(bytes(rng.choice(b"ab") for _ in range(rng.randint(200, 900))))
+    return out
+
+
+@pytest.mark.parametrize("name", ["ex1_plain", "ex6_plain", "ex9_plain", "ex3_reverse", "ex8_reverse", "ex5_bnf"])
+def test_lean_pass(emul, name, tmp_path):
+    """Strings without a periodic stretch (an empty region-table row) are handed to the lean walk -- the plain step only, walk_wave_lean --
+    through a queue; strings with stretches stay with the first pass.  Both kinds in one batch, several automata's worth of segments."""
+    rng = random.Random(11 + len(name))
+    blob = image.blob_from_dump(oracle_lib.load_dump(name))
+    path = tmp_path / "a.blob"
+    path.write_bytes(blob)
+    strings = text_without_stretches(rng, 30) + [b"a" * 700 + b"b", b"ab" * 300, b"a" * 255, b"b"]
+    rng.shuffle(strings)
+    want = oracle_lib.OracleImage(blob).match(strings)
+    p = subprocess.run([emul, str(path), "3", "1"], input=b"".join(s + b"\n" for s in strings), capture_output=True)
+    assert p.returncode == 0
+    assert [int(x) for x in p.stdout.split()] == list(want)
+    handed_on = int(p.stderr.decode().split(" of the strings walked by the lean pass")[0].split()[-1])
+    assert 40 <= handed_on <= 60                                    # the texts of 256 bytes and more; not the periodic ones, not the short ones

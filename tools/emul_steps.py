@@ -19,7 +19,7 @@ for name in names:
         for ws in (False, True):
             strings.append(prefix + corpus.pumped_string(n, pump) + (suffix if ws else ""))
     p = subprocess.run([exe, blob, "8", "1"], input=("\n".join(strings) + "\n").encode(), capture_output=True)
-    line = [l for l in p.stderr.decode().splitlines() if l.startswith("emul:")][0]
+    line = [l for l in p.stderr.decode().splitlines() if l.startswith("emul:") and "steps" in l][0]
     steps = int(line.split("steps ")[1].split(",")[0])
     tot += steps
     print("%-14s %s  answers %s" % (name, line[6:], p.stdout.decode().replace("\n", "")))
