@@ -2,8 +2,10 @@
 // automata.cpp:16-96 and mfa.cpp:11-77, freezing a graph into an automaton image, and match()
 // through the C-ABI of libmfa_hip.so.
 #include <algorithm>
+#include <cstdlib>
 #include <fstream>
 #include <stdexcept>
+#include <thread>
 
 #include "../../include/mfa_hip.h"
 #include "diploma_api.h"
@@ -159,9 +161,51 @@ mfa_image* Automata::image_for_match() {
     return cached_image_;
 }
 
+extern "C" int diploma_partition_by_bytes(const uint64_t* offsets, uint64_t n, uint32_t parts, uint64_t* cuts) {
+    if (!offsets || !cuts || parts == 0) return -1;
+    const uint64_t total = offsets[n] - offsets[0];
+    cuts[0] = 0;
+    for (uint32_t r = 1; r < parts; r++) {
+        // (128-bit product: a batch may hold more than 2^64 / parts bytes only in theory, but the rule should not depend on that)
+        const uint64_t target = offsets[0] + (uint64_t)(((unsigned __int128)total * r) / parts);
+        uint64_t k = (uint64_t)(std::lower_bound(offsets, offsets + n + 1, target) - offsets);
+        if (k < cuts[r - 1]) k = cuts[r - 1];
+        if (k > n) k = n;
+        cuts[r] = k;
+    }
+    cuts[parts] = n;
+    return 0;
+}
+
 void Automata::match_packed(const uint8_t* bytes, const uint64_t* offsets, uint64_t n, uint8_t* results) {
-    int rc = mfa_match_batch_host(image_for_match(), bytes, offsets, n, results, device);
-    if (rc != MFA_OK) fail("mfa_match_batch_host", rc);
+    mfa_image* img = image_for_match();
+    // the devices of the node: all of them by default (north_star: "the string batch shards trivially across the 8 GPUs of one node")
+    const int count = mfa_device_count();
+    int want = devices;
+    if (const char* e = getenv("DIPLOMA_DEVICES")) want = atoi(e);
+    unsigned use = count <= 0 ? 1u : (want <= 0 ? (unsigned)count : (unsigned)std::min(want, count));
+    unsigned shards = use;
+    if (const char* e = getenv("DIPLOMA_FORCE_SHARDS")) shards = (unsigned)std::max(1, atoi(e));      // (tests: several shards on the devices there are)
+    const uint64_t total = n ? offsets[n] - offsets[0] : 0;
+    if (shards <= 1 || (!getenv("DIPLOMA_FORCE_SHARDS") && (n < 2ull * shards || total < (4ull << 20)))) {
+        int rc = mfa_match_batch_host(img, bytes, offsets, n, results, device);
+        if (rc != MFA_OK) fail("mfa_match_batch_host", rc);
+        return;
+    }
+    vector<uint64_t> cuts(shards + 1);
+    diploma_partition_by_bytes(offsets, n, shards, cuts.data());
+    vector<int> rcs(shards, MFA_OK);
+    vector<std::thread> workers;
+    for (unsigned r = 0; r < shards; r++) {
+        if (cuts[r + 1] == cuts[r]) continue;
+        const int dev = (device + (int)(r % use)) % std::max(count, 1);
+        workers.emplace_back([&, r, dev]() {                      // (HIP's current device is per host thread; the C-ABI is re-entrant per device)
+            rcs[r] = mfa_match_batch_host(img, bytes, offsets + cuts[r], cuts[r + 1] - cuts[r], results + cuts[r], dev);
+        });
+    }
+    for (std::thread& t : workers) t.join();
+    for (unsigned r = 0; r < shards; r++)
+        if (rcs[r] != MFA_OK) fail("mfa_match_batch_host (one of the devices)", rcs[r]);
 }
 
 vector<bool> Automata::match_batch(const vector<string>& strs) {

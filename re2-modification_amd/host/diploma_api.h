@@ -142,7 +142,12 @@ public:
 
     // the automaton image handed to the device (include/mfa_image_format.h)
     virtual vector<uint8_t> image_blob() const;
-    int device = 0;    // HIP device the match calls run on
+    int device = 0;    // HIP device the match calls run on (the first one, when a batch is spread over several)
+    // How many HIP devices a packed batch is spread over: 0 = all the node has, 1 = `device` only.  Strings are independent: the batch is
+    // cut into contiguous ranges of about equal BYTES (diploma_partition_by_bytes), one host thread per device copies its range in,
+    // matches it through the C-ABI and copies the answers back into place; no exchange between devices.  Small batches (under 4 MiB, or
+    // fewer strings than twice the devices) go to `device` alone.  Environment: DIPLOMA_DEVICES=N overrides this field.
+    int devices = 0;
 
 protected:
     friend vector<vector<bool>> match_mixed(const vector<MFA*>& automata, const vector<vector<string>>& strs);
@@ -308,6 +313,11 @@ std::string substr(std::string originalString, int maxLength);
 void match(string regexp_str, bool reverse, bool bnf, bool ssnf, bool use_log = false);
 // matchers/match_mfa.cpp:13,58 counterparts: strings from a file (one per line), one batch, results and
 // timing on stdout
+// The cut points of a batch over `parts` devices: cuts[r] .. cuts[r+1]-1 are the strings of part r (parts + 1 values, cuts[0] = 0,
+// cuts[parts] = n), balanced by bytes -- the rule of mfa_amd/sharding.py: part r starts at the first string whose offset is at least
+// r / parts of the batch's bytes.  Returns 0, or -1 for bad arguments.
+extern "C" int diploma_partition_by_bytes(const uint64_t* offsets, uint64_t n, uint32_t parts, uint64_t* cuts);
+
 // several automata, one batch: strs[k] are matched against automata[k] (memory automata only) by ONE device call
 // (mfa_match_mixed: the region pre-pass and the walks of all of them scheduled together); results[k][j] = automata[k] matches strs[k][j]
 vector<vector<bool>> match_mixed(const vector<MFA*>& automata, const vector<vector<string>>& strs);
