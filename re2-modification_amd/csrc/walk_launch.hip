@@ -396,6 +396,22 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
     const bool gate = table && with_regions && ng > 1 && ng <= MFA_GATE_MAX_GROUPS && env_int("MFA_MIXED_GATE", 0) != 0 && gate_ready(*d);
     const uint32_t stamp = (uint32_t)(d->calls & 0xfffu);     // what every word of this call's table rows carries (the table buffer is rewritten by every call)
 
+    // One automaton, one group: exactly the single-automaton call (mfa_match_batch: region pass, then the walk, on the caller's stream, with the
+    // engine that call would choose) -- the hops to the internal streams and back cost such a batch 0.03-0.06 ms and buy it nothing.  (Cutting a
+    // 1.9 GB batch of ONE automaton into two or three groups was measured in round 4, configs[4]: 0.517 ms in one piece, 0.61 / 0.69 / 0.74
+    // ms in two / three / four groups: a walk launch is latency-bound, its 0.15 ms are paid per group and hide behind nothing that short.)
+    if (ns == 1 && ng == 1 && env_int("MFA_MIXED_SINGLE_DIRECT", 1) != 0) {
+        const uint32_t slot1 = (uint32_t)(d->calls % MIX_TIMINGS);
+        HIP_TRY(hipEventRecord(d->ev_r0[slot1], cs));
+        rc = mfa_match_batch(mx->images[0], d_bytes, d_offsets, n, d_results, device, stream);
+        HIP_TRY(hipEventRecord(d->ev_r1[slot1], cs));
+        HIP_TRY(hipEventRecord(d->ev_end[slot1], cs));
+        if (rc != MFA_OK) return rc;
+        d->timed = true; d->calls++; d->ng_last = 1;
+        d->last_region_launches = with_regions ? 1u : 0u; d->last_walk_launches = 1; d->last_groups = 1; d->last_gated = false;
+        return MFA_OK;
+    }
+
     // ---- the plan (table engine): one launch per group and run of consecutive segments whose automata have the same number of cells (a
     // launch's kernel and its LDS footprint are those of its largest cell count); groups alternate between the walk streams, so that a
     // group's walk may start while the one before it drains
