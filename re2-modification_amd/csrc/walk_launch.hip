@@ -84,6 +84,10 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     const int cap_waves = env_int("MFA_WALK_WAVES_PER_CU", 0);      // development knob (multiples of 4)
     if (cap_waves > 0 && (uint64_t)(cap_waves + 3) / 4 < per_cu) per_cu = (uint64_t)(cap_waves + 3) / 4;
     uint64_t grid = (uint64_t)(n_cus > 0 ? n_cus : 256) * per_cu, want = (n + 255) / 256;
+    {   // development: a fraction of the workgroups the device holds (fewer walk waves beside the region pass, each taking more tickets)
+        const int pct = env_int("MFA_WALK_GRID_PCT", 100);
+        if (pct > 0 && pct < 100) grid = std::max<uint64_t>(1, grid * (uint64_t)pct / 100u);
+    }
     if (grid > want) grid = want;
     // What a wave may spill (list entries and probe images beyond the LDS capacity) is sized for the worst case -- every node of the launch's
     // largest automaton alive at once -- per wave of the grid: 4.7 MB per wave for 1024 nodes and one cell.  The grid shrinks (the waves are

@@ -467,3 +467,23 @@ def test_gated_walks_see_fresh_tables(monkeypatch):
     # the tables themselves: the gated launch writes what per-group launches write
     monkeypatch.setenv("MFA_MIXED_GATE", "0")
     mx.close()
+
+
+@pytest.mark.parametrize("name,bound", [("ex8_reverse", 125.0), ("ex8_bnf", 60.0)])
+def test_executed_steps_of_the_77_node_automata(name, bound):
+    """BASELINE configs[4]'s worst line -- example 8 `-reverse` (77 nodes, reversed scan) on pump-only strings -- and the same automaton's
+    forward twin (`-bnf`): the walk must get through a string in a bounded number of EXECUTED steps whatever its length (1-64 KiB here:
+    1 900 MB of input, ~95 / ~40 steps per string), not in wall time: counted by the MFA_WALK_STATS build of the kernel (lane steps /
+    strings).  Round 3's probe control took 156 steps per string on the reversed automaton (periods tried in turn, a period that had
+    failed once kept for the rest of the string); the bound fails if the probes stop finding the list's own period."""
+    import re
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(oracle_lib.ROOT, "tools", "rev8_run.py"), "25000", "1", "1", name], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-1500:]
+    m = re.search(r"(\d+) strings, wave-iterations (\d+) \(dual (\d+)\), lane steps (\d+), skipped (\d+)", p.stderr)
+    assert m, p.stderr[-1500:]
+    strings, iters, dual, steps, skipped = (int(x) for x in m.groups())
+    assert strings == 25000 and "(25000 accepted)" in p.stdout
+    assert steps / strings <= bound, "%.1f executed steps per string" % (steps / strings)
+    assert skipped > 300 * steps                                      # nearly every character is jumped over
