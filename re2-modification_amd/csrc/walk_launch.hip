@@ -71,7 +71,10 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     const uint32_t c_cap = want_c > 0 ? (uint32_t)want_c : 8u;
     uint32_t C = std::min(p.max_live, c_cap);
     if (C < 1) C = 1;
-    const uint32_t wgs_goal = (uint32_t)env_int("MFA_WALK_WGS", 2);
+    // two workgroups per CU when the batch fills the device; a batch that does not even give every CU one workgroup leaves the LDS to that
+    // one: longer lists stay in LDS (the 77-node automata: lists of 10, three entries of them in LDS at two workgroups per CU)
+    const uint64_t cus_ = (uint64_t)(n_cus > 0 ? n_cus : 256);
+    const uint32_t wgs_goal = (uint32_t)env_int("MFA_WALK_WGS", (n + 255) / 256 <= cus_ ? 1 : 2);
     while (C > 1 && want_c <= 0 && a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max / wgs_goal) C--;
     while (C > 1 && a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max) C--;
     if (a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max) return MFA_ERR_UNSUPPORTED;      // the tables alone fill the LDS
