@@ -487,3 +487,29 @@ def test_executed_steps_of_the_77_node_automata(name, bound):
     assert strings == 25000 and "(25000 accepted)" in p.stdout
     assert steps / strings <= bound, "%.1f executed steps per string" % (steps / strings)
     assert skipped > 100 * steps                                      # nearly every character is jumped over
+
+
+def test_bench_under_torchrun_rehearsal():
+    """The driver's multi-GPU launch line, word for word -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W` -- with N = 2 ranks rehearsed on this one GPU over gloo
+    (MFA_BENCH_REHEARSE=1): bench.py must take RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the launcher, print ONE line on rank 0
+    and leave no rank behind."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = oracle_lib.ROOT
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env["MFA_BENCH_REHEARSE"] = "1"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--strings-per-example", "3000", "--no-secondary", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert p.returncode == 0, p.stderr[-2500:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["backend"] == "gloo" and d["strings_by_rank"] == [30000, 30000]
+    assert d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["value"] > 0
