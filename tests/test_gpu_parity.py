@@ -282,18 +282,26 @@ MFA_AUTOS = [a for a in MANIFEST["automata"] if not a["name"].startswith("nfa_")
 
 
 @pytest.mark.parametrize("auto", MFA_AUTOS, ids=lambda a: a["name"])
-def test_periodic_fuzz_against_oracle(auto):
+def test_periodic_fuzz_against_oracle(auto, monkeypatch):
     """Every memory automaton of the fixture set (plain, -bnf, -reverse images and the extra regexes, up to
-    three cells) on periodic inputs, against the CPU restatement."""
+    three cells) on periodic inputs, against the CPU restatement: the library's default engine and the table-driven walk (whose probe
+    control decides where jumps are tried: shape history, optimistic and chained dual periods).  MFA_FUZZ_SEEDS=n: n more seeds, longer strings."""
     blob = image.blob_from_dump(oracle_lib.load_dump(auto["name"]))
-    rng = np.random.default_rng(int.from_bytes(auto["name"].encode(), "little") % (2 ** 32))
     alphabet = b"abcd" if "d" in auto["regex"] else b"abc"
-    strings = _periodic_fuzz(rng, 128, 2500, alphabet)
-    want = oracle_lib.OracleImage(blob).match(strings)
-    got = gpu_match(capi.Image(blob), strings)
-    bad = np.nonzero(got != want)[0]
-    assert bad.size == 0, "%s: %d mismatches, first len %d %r want %d" % (
-        auto["name"], bad.size, len(strings[bad[0]]), strings[bad[0]][:80], want[bad[0]])
+    ora = oracle_lib.OracleImage(blob)
+    for seed in range(1 + int(os.environ.get("MFA_FUZZ_SEEDS", "0"))):
+        rng = np.random.default_rng((int.from_bytes(auto["name"].encode(), "little") + 7919 * seed) % (2 ** 32))
+        strings = _periodic_fuzz(rng, 128, 2500 if seed == 0 else 12000, alphabet)
+        want = ora.match(strings)
+        for engine in ("", "table"):
+            if engine:
+                monkeypatch.setenv("MFA_WALK", engine)
+            else:
+                monkeypatch.delenv("MFA_WALK", raising=False)
+            got = gpu_match(capi.Image(blob), strings)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, "%s seed %d engine %r: %d mismatches, first len %d %r want %d" % (
+                auto["name"], seed, engine, bad.size, len(strings[bad[0]]), strings[bad[0]][:80], want[bad[0]])
 
 
 @pytest.mark.parametrize("ex", range(1, 11))
