@@ -876,24 +876,82 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
 }
 
 // ---- the list one period ago (SB) and its movement (SA) ----------------------------------------------------------------------------------
-template <int K> WALK_DEV uint32_t sb_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.CI ? st.sb[(e * Lay<K>::W + w) * WALK_WV + wv_lane()] : st.gsb[((e - st.CI) * Lay<K>::W + w) * WALK_WV + wv_lane()]; }
-template <int K> WALK_DEV void sb_wr(const Store& st, uint32_t e, uint32_t w, uint32_t v) {
-    if (e < st.CI) st.sb[(e * Lay<K>::W + w) * WALK_WV + wv_lane()] = v; else st.gsb[((e - st.CI) * Lay<K>::W + w) * WALK_WV + wv_lane()] = v;
+// Whole entries at a time: ONE branch on where the entry's image lives (LDS below CI, the wave's area in global memory above), then W (or
+// DW) accesses with constant offsets from one address.  (Word by word -- a branch and an address per word -- the five functions below were
+// 18 % of a wave-iteration on the 77-node automata, whose lists are mostly in global memory.)
+template <int K> WALK_DEV void sb_rd_words(const Store& st, uint32_t e, uint32_t (&w)[Lay<K>::W]) {
+    if (e < st.CI) {
+        const WALK_LDS uint32_t* p = st.sb + (e * Lay<K>::W) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::W; k++) w[k] = p[k * WALK_WV];
+    } else {
+        const uint32_t* p = st.gsb + (size_t)((e - st.CI) * Lay<K>::W) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::W; k++) w[k] = p[k * WALK_WV];
+    }
 }
-template <int K> WALK_DEV uint32_t sa_rd(const Store& st, uint32_t e, uint32_t w) { return e < st.CI ? st.sa[(e * Lay<K>::DW + w) * WALK_WV + wv_lane()] : st.gsa[((e - st.CI) * Lay<K>::DW + w) * WALK_WV + wv_lane()]; }
-template <int K> WALK_DEV void sa_wr(const Store& st, uint32_t e, uint32_t w, uint32_t v) {
-    if (e < st.CI) st.sa[(e * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v; else st.gsa[((e - st.CI) * Lay<K>::DW + w) * WALK_WV + wv_lane()] = v;
+template <int K> WALK_DEV void sb_wr_words(const Store& st, uint32_t e, const uint32_t (&w)[Lay<K>::W]) {
+    if (e < st.CI) {
+        WALK_LDS uint32_t* p = st.sb + (e * Lay<K>::W) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::W; k++) p[k * WALK_WV] = w[k];
+    } else {
+        uint32_t* p = st.gsb + (size_t)((e - st.CI) * Lay<K>::W) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::W; k++) p[k * WALK_WV] = w[k];
+    }
+}
+template <int K> WALK_DEV void sa_rd_dwords(const Store& st, uint32_t e, uint32_t (&w)[Lay<K>::DW]) {
+    if (e < st.CI) {
+        const WALK_LDS uint32_t* p = st.sa + (e * Lay<K>::DW) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::DW; k++) w[k] = p[k * WALK_WV];
+    } else {
+        const uint32_t* p = st.gsa + (size_t)((e - st.CI) * Lay<K>::DW) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::DW; k++) w[k] = p[k * WALK_WV];
+    }
+}
+template <int K> WALK_DEV void sa_wr_dwords(const Store& st, uint32_t e, const uint32_t (&w)[Lay<K>::DW]) {
+    if (e < st.CI) {
+        WALK_LDS uint32_t* p = st.sa + (e * Lay<K>::DW) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::DW; k++) p[k * WALK_WV] = w[k];
+    } else {
+        uint32_t* p = st.gsa + (size_t)((e - st.CI) * Lay<K>::DW) * WALK_WV + wv_lane();
+#pragma unroll
+        for (uint32_t k = 0; k < Lay<K>::DW; k++) p[k * WALK_WV] = w[k];
+    }
 }
 
 // index of a value word's direction: 0 = P (in units of 16), 1 + 2c = S of cell c, 2 + 2c = L of cell c; word 1 has none
 WALK_DEV int dir_index(uint32_t w) { return w == 0u ? 0 : (int)w - 1; }
 
+// the movement of an entry since its image `b` was taken, as packed directions; wide: one does not fit 16 bits (or the first-cell name changed)
+template <int K> WALK_DEV void entry_movement(const uint32_t (&v)[Lay<K>::W], const uint32_t (&b)[Lay<K>::W], uint32_t (&nw)[Lay<K>::DW], bool& wide) {
+    int32_t d[2 * Lay<K>::DW];
+#pragma unroll
+    for (uint32_t k = 0; k < 2 * Lay<K>::DW; k++) d[k] = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < Lay<K>::W; w++) {
+        if (w == 1u) continue;
+        int32_t dv = (int32_t)(v[w] - b[w]);
+        if (w == 0u) { if (dv & 15) wide = true; dv >>= 4; }
+        d[dir_index(w)] = dv;
+        if (dv != (int32_t)(int16_t)dv) wide = true;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < Lay<K>::DW; k++) nw[k] = ((uint32_t)d[2 * k] & 0xffffu) | ((uint32_t)d[2 * k + 1] << 16);
+}
+
 // save list `cur` of the lanes in `pred`
 template <int K> WALK_DEV void image_save(const Store& st, uint32_t cur, bool pred, uint32_t n) {
     for (uint32_t e = 0; __any(pred && e < n); e++)
         if (pred && e < n) {
-#pragma unroll
-            for (uint32_t w = 0; w < Lay<K>::W; w++) { const uint32_t v = rd_v<K>(st, cur, e, w); sb_wr<K>(st, e, w, w == 1u ? (v & 0xffffu) : v); }
+            uint32_t v[Lay<K>::W];
+            rd_words<K>(st, cur, e, v);
+            v[1] &= 0xffffu;
+            sb_wr_words<K>(st, e, v);
         }
 }
 
@@ -904,27 +962,18 @@ template <int K> WALK_DEV void image_measure(const Store& st, uint32_t cur, bool
     if (pred && n != sb_n) { moved = true; vac = true; }
     for (uint32_t e = 0; __any(pred && e < n); e++)
         if (pred && e < n) {
-            int32_t d[2 * Lay<K>::DW];
+            uint32_t v[Lay<K>::W], b[Lay<K>::W], nw[Lay<K>::DW], sa[Lay<K>::DW];
+            rd_words<K>(st, cur, e, v);
+            v[1] &= 0xffffu;
+            sb_rd_words<K>(st, e, b);
+            sa_rd_dwords<K>(st, e, sa);
+            sb_wr_words<K>(st, e, v);
+            if (v[1] != b[1]) { vac = true; moved = true; }
+            entry_movement<K>(v, b, nw, wide);
 #pragma unroll
-            for (uint32_t k = 0; k < 2 * Lay<K>::DW; k++) d[k] = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < Lay<K>::W; w++) {
-                uint32_t v = rd_v<K>(st, cur, e, w);
-                if (w == 1u) v &= 0xffffu;
-                const uint32_t b = sb_rd<K>(st, e, w);
-                sb_wr<K>(st, e, w, v);
-                if (w == 1u) { if (v != b) { vac = true; moved = true; } continue; }
-                int32_t dv = (int32_t)(v - b);
-                if (w == 0u) { if (dv & 15) wide = true; dv >>= 4; }
-                d[dir_index(w)] = dv;
-                if (dv != (int32_t)(int16_t)dv) wide = true;
-            }
-#pragma unroll
-            for (uint32_t k = 0; k < Lay<K>::DW; k++) {
-                const uint32_t nw = ((uint32_t)d[2 * k] & 0xffffu) | ((uint32_t)d[2 * k + 1] << 16);
-                if (e >= sb_n || nw != sa_rd<K>(st, e, k)) moved = true;
-                sa_wr<K>(st, e, k, nw);
-            }
+            for (uint32_t k = 0; k < Lay<K>::DW; k++)
+                if (e >= sb_n || nw[k] != sa[k]) moved = true;
+            sa_wr_dwords<K>(st, e, nw);
         }
 }
 
@@ -932,8 +981,9 @@ template <int K> WALK_DEV void image_measure(const Store& st, uint32_t cur, bool
 template <int K> WALK_DEV void image_dirs(const Store& st, uint32_t cur, bool pred, uint32_t n) {
     for (uint32_t e = 0; __any(pred && e < n); e++)
         if (pred && e < n) {
-#pragma unroll
-            for (uint32_t k = 0; k < Lay<K>::DW; k++) wr_d<K>(st, cur, e, k, sa_rd<K>(st, e, k));
+            uint32_t sa[Lay<K>::DW];
+            sa_rd_dwords<K>(st, e, sa);
+            wr_dwords<K>(st, cur, e, sa);
         }
 }
 
@@ -942,25 +992,18 @@ template <int K> WALK_DEV bool image_same(const Store& st, uint32_t cur, bool pr
     bool same = pred && n == sb_n;
     for (uint32_t e = 0; __any(same && e < n); e++)
         if (same && e < n) {
-            uint32_t differs = 0u;
-            int32_t dv[2 * Lay<K>::DW];
-#pragma unroll
-            for (uint32_t k = 0; k < 2 * Lay<K>::DW; k++) dv[k] = 0;
-#pragma unroll
-            for (uint32_t w = 0; w < Lay<K>::W; w++) {
-                uint32_t v = rd_v<K>(st, cur, e, w);
-                const uint32_t b = sb_rd<K>(st, e, w);
-                if (w == 1u) { differs |= (v & 0xffffu) ^ b; continue; }
-                int32_t m = (int32_t)(v - b);
-                if (w == 0u) { differs |= (uint32_t)(m & 15); m >>= 4; }
-                dv[dir_index(w)] = m;
-                if (m != (int32_t)(int16_t)m) differs |= 1u;
-            }
+            uint32_t v[Lay<K>::W], b[Lay<K>::W], nw[Lay<K>::DW], sa[Lay<K>::DW], dd[Lay<K>::DW];
+            rd_words<K>(st, cur, e, v);
+            sb_rd_words<K>(st, e, b);
+            sa_rd_dwords<K>(st, e, sa);
+            rd_dwords<K>(st, cur, e, dd);
+            bool wide = false;
+            entry_movement<K>(v, b, nw, wide);
+            uint32_t differs = ((v[1] & 0xffffu) ^ b[1]) | (wide ? 1u : 0u);
 #pragma unroll
             for (uint32_t k = 0; k < Lay<K>::DW; k++) {
-                const uint32_t sa = sa_rd<K>(st, e, k);
-                differs |= sa ^ rd_d<K>(st, cur, e, k);                                                   // the direction was mapped to itself
-                differs |= sa ^ (((uint32_t)dv[2 * k] & 0xffffu) | ((uint32_t)dv[2 * k + 1] << 16));      // the list moved by it again
+                differs |= sa[k] ^ dd[k];                                                              // the direction was mapped to itself
+                differs |= sa[k] ^ nw[k];                                                              // the list moved by it again
             }
             if (differs) same = false;
         }
@@ -971,16 +1014,17 @@ template <int K> WALK_DEV bool image_same(const Store& st, uint32_t cur, bool pr
 template <int K> WALK_DEV void image_advance(const Store& st, uint32_t cur, bool pred, uint32_t n, uint32_t skip) {
     for (uint32_t e = 0; __any(pred && e < n); e++)
         if (pred && e < n) {
-            uint32_t dw[Lay<K>::DW];
-#pragma unroll
-            for (uint32_t k = 0; k < Lay<K>::DW; k++) dw[k] = rd_d<K>(st, cur, e, k);
+            uint32_t v[Lay<K>::W], dw[Lay<K>::DW];
+            rd_words<K>(st, cur, e, v);
+            rd_dwords<K>(st, cur, e, dw);
 #pragma unroll
             for (uint32_t w = 0; w < Lay<K>::W; w++) {
                 if (w == 1u) continue;
                 const int k = dir_index(w);
                 const int32_t d = d16(dw[k / 2], (uint32_t)k) * (w == 0u ? 16 : 1);
-                wr_v<K>(st, cur, e, w, rd_v<K>(st, cur, e, w) + skip * (uint32_t)d);
+                v[w] += skip * (uint32_t)d;
             }
+            wr_words<K>(st, cur, e, v);
         }
 }
 
