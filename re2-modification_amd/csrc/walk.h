@@ -26,6 +26,7 @@ struct WalkArgs {                     // kernel parameters; every pointer is a d
     uint32_t n_seg, C, CX, accel, refill;
     uint32_t images_global;           // the two probe images of a lane live in global memory (less LDS per wave: more waves per CU)
     uint32_t gate;                    // 0, or 0x1000 | stamp: the region table is being written while the kernel runs, rows carry this stamp (regions.hip: GATE)
+    uint32_t nm_words;                // long-list kernel (WALK_NODE_MAP): words of a lane's node map = (nodes of the launch's largest automaton + 3) / 4, else 0
     uint32_t* lean_queue;             // strings without a periodic stretch are handed to walk_lean_kernel through this queue (nullptr: all are walked here);
                                       //   its length is counter[1] (as 32 bits), the lean kernel's ticket counter counter[2]
     uint32_t* lean_seen;              // pinned host word (or nullptr): the lean kernel stores the queue's length + 1 there (mfa_internal.h: LeanHint)

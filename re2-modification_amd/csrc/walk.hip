@@ -56,7 +56,8 @@ walk_kernel(WalkArgs a) {
     }
     constexpr uint32_t W = Lay<K>::W, DW = Lay<K>::DW;
     const uint32_t CI = a.images_global ? 0u : a.C, XI = a.CX + a.C - CI;      // image entries in LDS / in global memory
-    const uint32_t per_wave = a.C * 64u * (2u * W + 2u * DW) + CI * 64u * (W + DW) + 2u * 64u * MFA_RT_CACHED;
+    const uint32_t nm_words = WALK_NODE_MAP ? a.nm_words : 0u;      // the lanes' node maps (long-list kernel)
+    const uint32_t per_wave = a.C * 64u * (2u * W + 2u * DW) + CI * 64u * (W + DW) + 2u * 64u * MFA_RT_CACHED + nm_words * 64u;
     // the wave's number as a scalar: everything derived from it stays in scalar registers
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave);
     WALK_LDS uint32_t* base = (WALK_LDS uint32_t*)smem + a.shared_words + wave_u * per_wave;
@@ -66,7 +67,8 @@ walk_kernel(WalkArgs a) {
     st.ld = base; base += 2u * a.C * DW * 64u;
     st.sb = base; base += CI * W * 64u;
     st.sa = base; base += CI * DW * 64u;
-    WALK_LDS uint64_t* const rtc = (WALK_LDS uint64_t*)base;
+    WALK_LDS uint64_t* const rtc = (WALK_LDS uint64_t*)base; base += 2u * 64u * MFA_RT_CACHED;
+    st.nm = (WALK_LDS uint8_t*)base; st.nm_words = nm_words;
     const uint64_t gwave = (uint64_t)blockIdx.x * 4u + wave_u;
     uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * (2u * W + 2u * DW) + (uint64_t)XI * 64u * (W + DW) + CMP_CACHE * 4u * 64u);
     st.gv = g; g += 2u * a.CX * W * 64u;
@@ -130,7 +132,9 @@ walk_lean_kernel(WalkArgs a) {
     const uint32_t wave_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     Store st;
     st.C = a.C; st.CX = a.CX; st.CI = 0u;
-    st.lv = (WALK_LDS uint32_t*)smem + a.shared_words + wave_u * (2u * a.C * W * 64u);
+    const uint32_t nm_words = WALK_NODE_MAP ? a.nm_words : 0u;
+    st.lv = (WALK_LDS uint32_t*)smem + a.shared_words + wave_u * (2u * a.C * W * 64u + nm_words * 64u);
+    st.nm = (WALK_LDS uint8_t*)(st.lv + 2u * a.C * W * 64u); st.nm_words = nm_words;
     st.ld = nullptr; st.sb = nullptr; st.sa = nullptr;
     const uint64_t gwave = (uint64_t)blockIdx.x * 4u + wave_u;
     uint32_t* g = a.spill + gwave * ((uint64_t)a.CX * 64u * 2u * W + CMP_CACHE * 4u * 64u);
@@ -147,8 +151,8 @@ walk_lean_kernel(WalkArgs a) {
 #define WALK_CAT(a, b) WALK_CAT2(a, b)
 
 // words of LDS one wave needs at capacity C
-static size_t wave_words(uint32_t C, bool images_global) {
-    return (size_t)C * 64u * ((images_global ? 2u : 3u) * (Lay<WALK_K>::W + Lay<WALK_K>::DW)) + 2u * 64u * MFA_RT_CACHED;
+static size_t wave_words(uint32_t C, bool images_global, uint32_t nm_words = 0) {
+    return (size_t)C * 64u * ((images_global ? 2u : 3u) * (Lay<WALK_K>::W + Lay<WALK_K>::DW)) + 2u * 64u * MFA_RT_CACHED + (WALK_NODE_MAP ? (size_t)nm_words * 64u : 0u);
 }
 
 #if WALK_STATS
@@ -160,7 +164,7 @@ int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
 #endif
     WalkArgs a = L.args;
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = ((size_t)a.shared_words + 4u * wave_words(a.C, a.images_global != 0u)) * 4u;
+    const size_t lds = ((size_t)a.shared_words + 4u * wave_words(a.C, a.images_global != 0u, a.nm_words)) * 4u;
     if (lds > 160u * 1024u) return MFA_ERR_UNSUPPORTED;
     hipError_t e = hipSuccess;
 #define WALK_GO(REVV, TGV)                                                                                                                   \
@@ -178,7 +182,7 @@ int WALK_CAT(launch_walk_k, WALK_K)(const WalkLaunch& L, void* stream) {
         WalkArgs al = a;
         al.C = L.lean_C;
         al.CX = a.CX + a.C > al.C ? a.CX + a.C - al.C : 1u;
-        const size_t lds_l = ((size_t)a.shared_words + 4u * (size_t)al.C * 64u * 2u * Lay<WALK_K>::W) * 4u;
+        const size_t lds_l = ((size_t)a.shared_words + 4u * ((size_t)al.C * 64u * 2u * Lay<WALK_K>::W + (WALK_NODE_MAP ? (size_t)a.nm_words * 64u : 0u))) * 4u;
 #define WALK_GO_LEAN(REVV, TGV)                                                                                                              \
     do {                                                                                                                                     \
         e = hipFuncSetAttribute((const void*)walk_lean_kernel<WALK_K, REVV, TGV, WALK_KEYS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l); \

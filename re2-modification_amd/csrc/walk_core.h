@@ -50,6 +50,9 @@
 #ifndef WALK_PROBE_PERIODS
 #define WALK_PROBE_PERIODS 5u
 #endif
+#ifndef WALK_NODE_MAP
+#define WALK_NODE_MAP 0      /* 1: the kernel for long lists (walk.hip: WALK_LONG_LISTS) finds a node's entry through a per-lane map in LDS */
+#endif
 #ifndef WALK_LEAN_MIN_LEN
 #define WALK_LEAN_MIN_LEN 256u      /* shorter strings are not worth a second look */
 #endif
@@ -392,7 +395,13 @@ struct Store {               // wave-uniform bases; every access adds the lane
     uint32_t* gq;            // global [CMP_CACHE][4][WV]  long comparisons answered for the step in progress: a, b, l, equal
     uint32_t C, CX;
     uint32_t CI;             // entries of the two probe images that are in LDS (C, or 0: the images live in global memory)
+    // WALK_NODE_MAP: where in the list being built does node x have its entry?  One byte per node and lane in LDS, [node / 4][lane][node % 4] (a
+    // lane's column is cleared with one word per four nodes): 0xff = nowhere, else position | list << 7.  A position of the list being READ
+    // is stale the moment its entry has been read (the entry clears it then), so "nowhere" and "in the other list" are the same answer.
+    WALK_LDS uint8_t* nm;
+    uint32_t nm_words;       // words of a lane's column: (nodes of the launch's largest automaton + 3) / 4
 };
+WALK_DEV uint32_t nm_at(uint32_t node) { return ((node >> 2) * WALK_WV + wv_lane()) * 4u + (node & 3u); }
 
 // single words (the images of a probe use them: rare)
 template <int K> WALK_DEV uint32_t rd_v(const Store& st, uint32_t l, uint32_t e, uint32_t w) {
@@ -712,7 +721,20 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
     if (pred) WALK_EV(2);
     uint32_t at = ~0u, old_id = 0u;
     U old = konst<U>(0u);
-    constexpr uint32_t NK = KeyCache<U>::N;
+    constexpr uint32_t NK = WALK_NODE_MAP ? 0u : KeyCache<U>::N;
+#if WALK_NODE_MAP
+    // the node's entry in the list being built, if it has one: one byte of the lane's map instead of a search through keys and list (lists of
+    // 10-18 entries on the 77-node automata: eight keys in registers, a compare-and-select chain per insertion, a loop behind them)
+    uint32_t old_tie = 0u;
+    if (pred) {
+        const uint32_t m = cx.st.nm[nm_at(node)];
+        if (m != 0xffu && (m >> 7) == cx.nxt) {
+            at = m & 0x7fu;
+            old_tie = rd_v<K>(cx.st, cx.nxt, at, 1) >> 16;
+            setv(old, rd_v<K>(cx.st, cx.nxt, at, 0));
+        }
+    }
+#else
     // (slots the list has not reached hold node 0xffff, which no automaton has; lanes outside `pred` find whatever they find: every use of
     // `at` below asks for pred)
 #pragma unroll
@@ -733,6 +755,7 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
             if (look && ((x & 0xffffu) >> vbits) == node) { at = j; old_tie = x >> 16; setv(old, rd_v<K>(cx.st, cx.nxt, j, 0)); }
         }
     }
+#endif
     bool win = pred;
     if (pred && at != ~0u) {
         load_pdir<K>(cx.st, cx.nxt, at, cx.dual_lane, old);
@@ -742,7 +765,12 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
         if (win && at == ~0u && cx.n_next >= NK) cx.keys.seen |= 1ull << (node & 63u);
     }
     if (win) {
-        if (at == ~0u) at = cx.n_next++;
+        if (at == ~0u) {
+            at = cx.n_next++;
+#if WALK_NODE_MAP
+            cx.st.nm[nm_at(node)] = (uint8_t)((cx.nxt << 7) | at);
+#endif
+        }
         t.P = P; t.vid = vid;
         store_entry<U, K>(cx.st, cx.nxt, at, t, tie, cx.fits);
 #pragma unroll
@@ -750,6 +778,18 @@ WALK_DEV void insert(StepCtx<U, K>& cx, bool pred, uint32_t vid, uint32_t vbits,
             if (at == k) { cx.keys.id[k] = node | (tie << 16); cx.keys.P[k] = val(P); }
     }
 }
+
+#if WALK_NODE_MAP
+// A step that is executed again (the wave has answered what its first execution asked for) builds its list anew: the places the abandoned
+// list holds in the lanes' maps are given back first.
+template <int K> WALK_DEV void map_forget(const Store& st, uint32_t vbits, uint32_t l, bool pred, uint32_t n) {
+    for (uint32_t j = 0; __any(pred && j < n); j++)
+        if (pred && j < n) {
+            WALK_LDS uint8_t* const mp = st.nm + nm_at((rd_v<K>(st, l, j, 1) & 0xffffu) >> vbits);
+            if (*mp == (uint8_t)((l << 7) | j)) *mp = 0xffu;
+        }
+}
+#endif
 
 template <int K, class TP>
 WALK_DEV void ee_decode(TP T, uint32_t at, bool p, uint32_t& e0, uint32_t& actions, uint32_t& cm, uint32_t& com, uint32_t& rdm) {
@@ -811,6 +851,12 @@ WALK_STEP_ATTR void walk_step(const Store& st, TP T, const Aut& au, WIn& in, uin
         const bool wait = live && !final_pass && !here;
         const uint32_t vi = have ? T[au.vinfo() + E.vid] : 0u;
         const uint32_t node = E.vid >> au.vbits();
+#if WALK_NODE_MAP
+        if (have) {                                                  // this entry has been read: its place in the map is free (unless the list being built has taken it)
+            WALK_LDS uint8_t* const mp = st.nm + nm_at(node);
+            if (*mp == (uint8_t)((cur << 7) | e)) *mp = 0xffu;
+        }
+#endif
         if (have) {                                                  // (a state the scan has passed counts as far ahead: it only holds its node)
             const uint32_t ahead = val(pos) - val(i);
             sh = ((sh << 7) | (sh >> 25)) ^ (E.vid * 4u + (ahead < 3u ? ahead : 3u) + 0x9e37u);
@@ -1170,6 +1216,9 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
                             aut_load(au, T, b.n_seg ? b.seg_table[seg] : 0u);
                             i = 0; accept = false; active = true; probe_at = 0;
                             P.reset(); hist.reset();
+#if WALK_NODE_MAP
+                            for (uint32_t k = 0; k < st.nm_words; k++) reinterpret_cast<WALK_LDS uint32_t*>(st.nm)[k * WALK_WV + wv_lane()] = 0xffffffffu;
+#endif
                             stable = false; patient = false;
                             n_cur = 1;                                // the list: (pos 0, start, no cells)  mfa.cpp:217-219
                             Ent<uint32_t, K> e0;
@@ -1266,6 +1315,9 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
             }
             if (!__any(active && in.rq != 0u)) break;
             answer_requests<REV>(st, in, active);
+#if WALK_NODE_MAP
+            map_forget<K>(st, au.vbits(), cur ^ 1u, active, n_next);
+#endif
         }
         cur ^= 1u;
         if (active) { n_cur = n_next; hist.push(shape); }
@@ -1398,6 +1450,9 @@ WALK_DEV void walk_wave_lean(const Batch& b, TP T, const Store& st, Feeder& feed
                             if (s >= b.seg_first[k]) seg = k;
                         aut_load(au, T, b.n_seg ? b.seg_table[seg] : 0u);
                         i = 0; accept = false; active = true;
+#if WALK_NODE_MAP
+                        for (uint32_t k = 0; k < st.nm_words; k++) reinterpret_cast<WALK_LDS uint32_t*>(st.nm)[k * WALK_WV + wv_lane()] = 0xffffffffu;
+#endif
                         n_cur = 1;                                    // the list: (pos 0, start, no cells)  mfa.cpp:217-219
                         Ent<uint32_t, K> e0;
                         e0.P = 0u; e0.vid = aut_start(T, au);
@@ -1423,6 +1478,9 @@ WALK_DEV void walk_wave_lean(const Batch& b, TP T, const Store& st, Feeder& feed
             walk_step<uint32_t, K, REV, TP>(st, T, au, in, cur, n_cur, n_next, i, len, ch, final_pass, active, false, accept, f2, TB, shape);
             if (!__any(active && in.rq != 0u)) break;
             answer_requests<REV>(st, in, active);
+#if WALK_NODE_MAP
+            map_forget<K>(st, au.vbits(), cur ^ 1u, active, n_next);
+#endif
         }
         cur ^= 1u;
         if (active) {

@@ -31,7 +31,8 @@ int walk_mode() {
     return !e ? 0 : e[0] == 't' ? 1 : e[0] == 'j' ? 2 : 0;     // "table" / "jit"; anything else: automatic
 }
 
-static size_t wave_words(uint32_t K, uint32_t C, bool ig) {
+static size_t wave_words(uint32_t K, uint32_t C, bool ig, uint32_t nm_words = 0) {
+    if (nm_words != 0u && K == 1u) return walk_wave_words_k1(C, ig) + (size_t)nm_words * 64u;      // the long-list kernel's node maps
     switch (K) {
         case 1: return walk_wave_words_k1(C, ig); case 2: return walk_wave_words_k2(C, ig); case 3: return walk_wave_words_k3(C, ig);
         case 4: return walk_wave_words_k4(C, ig); case 5: return walk_wave_words_k5(C, ig); case 6: return walk_wave_words_k6(C, ig);
@@ -75,12 +76,16 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     // one: longer lists stay in LDS (the 77-node automata: lists of 10, three entries of them in LDS at two workgroups per CU)
     const uint64_t cus_ = (uint64_t)(n_cus > 0 ? n_cus : 256);
     const uint32_t wgs_goal = (uint32_t)env_int("MFA_WALK_WGS", (n + 255) / 256 <= cus_ ? 1 : 2);
-    while (C > 1 && want_c <= 0 && a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max / wgs_goal) C--;
-    while (C > 1 && a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max) C--;
-    if (a.shared_words + 4u * wave_words(p.K, C, ig) > lds_max) return MFA_ERR_UNSUPPORTED;      // the tables alone fill the LDS
+    // one-cell automata with long lists (the 77-node ex. 8 -bnf / -reverse) have a kernel of their own, which finds a node's entry through a
+    // per-lane map in LDS: one byte per node and lane (automata of up to 128 nodes; beyond them the general kernel's key search)
+    const bool long_lists = p.K == 1 && p.max_live > 16u && p.max_live < 128u && env_int("MFA_WALK_LONG", 1) != 0 && getenv("MFA_WALK_STATS") == nullptr;
+    a.nm_words = long_lists ? (p.max_live + 1u + 3u) / 4u : 0u;
+    while (C > 1 && want_c <= 0 && a.shared_words + 4u * wave_words(p.K, C, ig, a.nm_words) > lds_max / wgs_goal) C--;
+    while (C > 1 && a.shared_words + 4u * wave_words(p.K, C, ig, a.nm_words) > lds_max) C--;
+    if (a.shared_words + 4u * wave_words(p.K, C, ig, a.nm_words) > lds_max) return MFA_ERR_UNSUPPORTED;      // the tables alone fill the LDS
     a.C = C;
     a.CX = p.max_live > C ? p.max_live - C : 1u;
-    const size_t lds_words = a.shared_words + 4u * wave_words(p.K, C, ig);
+    const size_t lds_words = a.shared_words + 4u * wave_words(p.K, C, ig, a.nm_words);
     uint64_t per_cu = lds_max / lds_words;
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
@@ -120,7 +125,7 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
         }
     }
     if (want_lean) {
-        const size_t lean_wave_words = (size_t)a.C * 64u * 2u * W;
+        const size_t lean_wave_words = (size_t)a.C * 64u * 2u * W + (size_t)a.nm_words * 64u;
         uint64_t lean_per_cu = lds_max / (a.shared_words + 4u * lean_wave_words);
         if (lean_per_cu > 4) lean_per_cu = 4;
         if (lean_per_cu >= 1) {
@@ -146,7 +151,7 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
         if (rc == MFA_OK) { (void)hipStreamSynchronize((hipStream_t)stream); walk_print_stats(d_counter, "walk"); }
         return rc;
     }
-    if (p.K == 1 && p.max_live > 16u && env_int("MFA_WALK_LONG", 1) != 0) return launch_walk_long_k1(L, stream);
+    if (long_lists) return launch_walk_long_k1(L, stream);
     switch (p.K) {
         case 1: return launch_walk_k1(L, stream); case 2: return launch_walk_k2(L, stream); case 3: return launch_walk_k3(L, stream);
         case 4: return launch_walk_k4(L, stream); case 5: return launch_walk_k5(L, stream); case 6: return launch_walk_k6(L, stream);

@@ -90,6 +90,8 @@ static void run(const Batch& b, const std::vector<uint32_t>& T, uint32_t C, uint
     std::vector<uint32_t> lv(2 * C * Lay<K>::W, 0xdeadbeefu), ld(2 * C * Lay<K>::DW, 0xdeadbeefu), sb(C * Lay<K>::W, 0xdeadbeefu), sa(C * Lay<K>::DW, 0xdeadbeefu),
         gv(2 * CX * Lay<K>::W, 0xdeadbeefu), gd(2 * CX * Lay<K>::DW, 0xdeadbeefu), gsb(CX * Lay<K>::W, 0xdeadbeefu), gsa(CX * Lay<K>::DW, 0xdeadbeefu), gq(CMP_CACHE * 4, 0xdeadbeefu);
     Store st;
+    std::vector<uint32_t> nm((CM + 1u + 3u) / 4u + 1u, 0xdeadbeefu);      // WALK_NODE_MAP builds: the lane's node map
+    st.nm = reinterpret_cast<uint8_t*>(nm.data()); st.nm_words = (CM + 1u + 3u) / 4u;
     st.lv = lv.data(); st.ld = ld.data(); st.sb = sb.data(); st.sa = sa.data(); st.gv = gv.data(); st.gd = gd.data(); st.gsb = gsb.data(); st.gsa = gsa.data(); st.gq = gq.data(); st.CI = C; st.C = C; st.CX = CX;
     uint64_t rtc[MFA_RT_CACHED] = {0};
     SeqFeeder feed;

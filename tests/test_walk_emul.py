@@ -22,6 +22,14 @@ def emul(tmp_path_factory):
     return exe
 
 
+@pytest.fixture(scope="module")
+def emul_map(tmp_path_factory):
+    """the same source as the kernel for long lists compiles it: WALK_NODE_MAP=1 (a node's entry found through a per-lane map, walk_core.h: insert)"""
+    exe = str(tmp_path_factory.mktemp("emul_map") / "walk_emul")
+    subprocess.check_call([os.path.join(EMUL_DIR, "build.sh"), exe], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, EMUL_FLAGS="-DWALK_NODE_MAP=1"))
+    return exe
+
+
 def mfa_names():
     names = []
     for p in sorted(glob.glob(os.path.join(oracle_lib.GOLDEN, "images", "*.dump"))):
@@ -75,6 +83,23 @@ def test_walk_source_against_oracle(emul, name, tmp_path):
     # (list capacity, regions): capacity 2-3 makes most lists spill; with regions the lane jumps over periodic stretches
     for cap, accel in ((8, 0), (2, 0), (8, 1), (3, 1)):
         got = run_emul(emul, [path, cap, accel], strings)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, "%s capacity %d regions %d: %d mismatches, first %r want %d got %d" % (
+            name, cap, accel, bad.size, strings[bad[0]][:60], want[bad[0]], got[bad[0]])
+
+
+@pytest.mark.parametrize("name", mfa_names())
+def test_walk_source_with_node_map(emul_map, name, tmp_path):
+    """the long-list kernel's form of the insertion (WALK_NODE_MAP) on every memory automaton, spilling lists and re-executed steps included"""
+    rng = random.Random(hash(name) & 0xfff)
+    blob = image.blob_from_dump(oracle_lib.load_dump(name))
+    path = tmp_path / "a.blob"
+    path.write_bytes(blob)
+    strings = [s for s in oracle_lib.load_set("abc7")[::11] + oracle_lib.load_set("rnd")[:200] + oracle_lib.load_set("odd") if s and b"\n" not in s]
+    strings += long_strings(name, rng) + text_without_stretches(rng, 6)
+    want = oracle_lib.OracleImage(blob).match(strings)
+    for cap, accel in ((2, 0), (3, 1)):
+        got = run_emul(emul_map, [path, cap, accel], strings)
         bad = np.nonzero(got != want)[0]
         assert bad.size == 0, "%s capacity %d regions %d: %d mismatches, first %r want %d got %d" % (
             name, cap, accel, bad.size, strings[bad[0]][:60], want[bad[0]], got[bad[0]])
