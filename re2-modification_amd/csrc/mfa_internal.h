@@ -44,8 +44,9 @@ int tabulate_nfa(HostImage& img);                                    // fills th
 // that safe) or once its `done` event has completed, so launches of one image that overlap on different
 // streams or from different host threads never share a counter, a scratch buffer or an event.
 // Whether the lean kernel behind a table walk (walk.hip: strings without periodic stretches) has had anything to do lately: the kernel
-// reports the length of its queue (+ 1) to a word of pinned host memory, and a launch whose slot saw two empty queues in a row leaves
-// the lean kernel and the queue out (one launch less on the stream) -- except every eighth time, to notice when the input changes.
+// reports the length of its queue (+ 1) to a word of pinned host memory, and a launch whose slot last saw an empty queue leaves the lean
+// kernel and the queue out (an empty launch beside a region pass costs the stream 0.1-0.35 ms: its workgroups queue for room) -- except
+// every 32nd time, with a quarter of the grid, to notice when the input changes.
 struct LeanHint {
     uint32_t* h_seen = nullptr;      // pinned, device-visible; 0 = nothing reported yet
     uint32_t quiet = 0, launches = 0;

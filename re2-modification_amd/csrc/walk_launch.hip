@@ -111,15 +111,22 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     // workgroups per CU where the LDS allows; its waves' spill areas and the queue of string numbers share the buffer with this launch's
     L.lean_grid = 0; L.lean_C = a.C;
     size_t lean_bytes = 0, queue_at = 0;
+    // (An EMPTY lean launch is not free beside a region pass: its workgroups -- 128 VGPRs, LDS for the tables and the lists -- queue for room like any
+    // other; 0.1-0.35 ms of the walk stream's time were measured for launches that had nothing to do.  So a launch whose slot last reported an empty
+    // queue leaves the lean kernel and the queue out, and looks again every 32nd time only, with a quarter of the grid.)
     bool want_lean = d_regions != nullptr && a.accel != 0u && env_int("MFA_WALK_LEAN", 1) != 0;
+    bool lean_probe = false;
     if (want_lean && lean != nullptr) {
         if (lean->h_seen == nullptr && hipHostMalloc((void**)&lean->h_seen, sizeof(uint32_t), hipHostMallocMapped) == hipSuccess) *lean->h_seen = 0u;
         if (lean->h_seen == nullptr) (void)hipGetLastError();
         else {
-            const uint32_t seen = *(volatile uint32_t*)lean->h_seen;      // what the last lean kernel of this slot that has ended found (+ 1)
+            const uint32_t seen = *(volatile uint32_t*)lean->h_seen;      // what the last lean kernel of this slot that has ended found (+ 1; 0: none has reported yet)
             lean->quiet = seen == 1u ? lean->quiet + 1u : 0u;
-            if (seen != 1u) lean->quiet = 0u;
-            if (lean->quiet >= 2u && (lean->launches & 7u) != 0u && env_int("MFA_WALK_LEAN", 1) != 2) want_lean = false;      // (MFA_WALK_LEAN=2: always)
+            if (lean->quiet >= 1u && env_int("MFA_WALK_LEAN", 1) != 2) {      // (MFA_WALK_LEAN=2: always)
+                if ((lean->launches & 31u) != 0u) want_lean = false; else lean_probe = true;
+            }
+            if (getenv("MFA_VERBOSE")) fprintf(stderr, "mfa_hip: table walk of %llu strings: last lean queue seen %d, launch %u: lean kernel %s\n",
+                                               (unsigned long long)n, (int)seen - 1, lean->launches, want_lean ? (lean_probe ? "on (a look)" : "on") : "left out");
             lean->launches++;
             a.lean_seen = lean->h_seen;
         }
@@ -130,6 +137,7 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
         if (lean_per_cu > 4) lean_per_cu = 4;
         if (lean_per_cu >= 1) {
             uint64_t lg = (uint64_t)(n_cus > 0 ? n_cus : 256) * lean_per_cu;
+            if (lean_probe) lg = std::max<uint64_t>(1, lg / 4u);
             if (lg > want) lg = want;
             const size_t lean_per_wave = ((size_t)(a.CX + a.C) * 64u * 2u * W + 4u * 4u * 64u) * sizeof(uint32_t);
             while (lg > 1 && lg * 4u * lean_per_wave > budget) lg = (lg + 1) / 2;
