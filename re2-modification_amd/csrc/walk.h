@@ -46,7 +46,7 @@ struct WalkLaunch {
 #define MFA_WALK_DECL(K) int launch_walk_k##K(const WalkLaunch& L, void* stream); size_t walk_wave_words_k##K(uint32_t C, bool images_global);
 MFA_WALK_DECL(1) MFA_WALK_DECL(2) MFA_WALK_DECL(3) MFA_WALK_DECL(4) MFA_WALK_DECL(5) MFA_WALK_DECL(6) MFA_WALK_DECL(7) MFA_WALK_DECL(8) MFA_WALK_DECL(9)
 #undef MFA_WALK_DECL
-int launch_walk_long_k1(const WalkLaunch& L, void* stream);   // K = 1 with eight cached keys: automata whose lists are long (77-node ex. 8 -bnf / -reverse)
+int launch_walk_long_k1(const WalkLaunch& L, void* stream);   // K = 1, automata of 17-128 nodes whose lists are long (77-node ex. 8 -bnf / -reverse): a node's entry is found through a per-lane map in LDS (WALK_NODE_MAP)
 int launch_walk_stats(const WalkLaunch& L, void* stream);      // K = 1 with counters (MFA_WALK_STATS=1; development)
 void walk_print_stats(unsigned long long* d_counter, const char* tag);
 

@@ -695,7 +695,7 @@ WALK_DEV void answer_requests(const Store& st, WIn& in, bool active) {
 #endif
 constexpr uint32_t KEYS = WALK_KEYS;      // entries of the list being built whose keys are also kept in registers (plain steps; eight of them cost
                                   // four more registers at the kernel's peak -- one region wave fewer beside two walk waves --: automata with long lists get a kernel
-                                  // of their own with eight, walk.hip)
+                                  // of their own, which finds entries through a node map instead: WALK_NODE_MAP, walk.hip)
 template <class U> struct KeyCache;
 template <> struct KeyCache<uint32_t> {
     static constexpr uint32_t N = KEYS;
