@@ -1133,6 +1133,13 @@ struct ProbeCtl {
 // LIST (a multiple of the input's) is read off instead of being guessed.  A jump skips whole periods of a list whose shape has that period:
 // the history stays valid across it.
 constexpr uint32_t HIST_MAX_P = 10u, HIST_N = 12u;
+// does q (1..8) divide p (0..15)?  A bit of two constants (an integer remainder is ~40 instructions, and this sits in every iteration of a lane that is
+// waiting to probe)
+WALK_DEV bool divides_small(uint32_t q, uint32_t p) {
+    const uint64_t lo = 0xffffull | (0x5555ull << 16) | (0x9249ull << 32) | (0x1111ull << 48);      // q = 1, 2, 3, 4: bit p of a 16-bit field
+    const uint64_t hi = 0x8421ull | (0x1041ull << 16) | (0x4081ull << 32) | (0x0101ull << 48);      // q = 5, 6, 7, 8
+    return (((q <= 4u ? lo : hi) >> ((((q - 1u) & 3u) << 4) + (p & 15u))) & 1ull) != 0ull;
+}
 struct ShapeHist {
     uint64_t h;
     WALK_DEV void reset() { h = 0ull; }
@@ -1147,12 +1154,19 @@ struct ShapeHist {
         if (p + 2u > c) return false;
         return ((h ^ (h >> (5u * p))) & 1023ull) == 0ull;
     }
-    // the smallest multiple p of q with pmin <= p <= HIST_MAX_P that the history supports; 0: none (yet)
+    // the smallest multiple p of q with pmin <= p <= HIST_MAX_P that the history supports; 0: none (yet).  Straight-line: the lags 1..10 that
+    // repeat as a bit mask, the multiples of q, the lags the history is long enough for, those not below pmin -- and the lowest bit left.
     WALK_DEV uint32_t period(uint32_t q, uint32_t pmin) const {
-        uint32_t found = 0u;
-        for (uint32_t p = q; p <= HIST_MAX_P; p += q)
-            if (found == 0u && p >= pmin && lag(p)) found = p;
-        return found;
+        const uint32_t c = (uint32_t)(h >> 60);
+        uint32_t m = 0u;
+#pragma unroll
+        for (uint32_t p = 1; p <= HIST_MAX_P; p++)
+            if (((h ^ (h >> (5u * p))) & 1023ull) == 0ull) m |= 1u << p;
+        const uint64_t lo = 0xffffull | (0x5555ull << 16) | (0x9249ull << 32) | (0x1111ull << 48), hi = 0x8421ull | (0x1041ull << 16) | (0x4081ull << 32) | (0x0101ull << 48);
+        m &= (uint32_t)((q <= 4u ? lo : hi) >> (((q - 1u) & 3u) << 4)) & 0xffffu;       // multiples of q
+        m &= c >= 3u ? (1u << (c - 1u)) - 2u : 0u;                                        // p + 2 <= c, p >= 1
+        m &= ~((1u << (pmin < 16u ? pmin : 16u)) - 1u);                                   // p >= pmin
+        return m ? (uint32_t)__builtin_ctz(m) : 0u;
     }
 };
 
@@ -1283,7 +1297,7 @@ WALK_DEV void walk_wave(const Batch& b, TP T, const Store& st, WALK_LDS uint64_t
             bool begin = false;
             if (want_p != 0u || (q != 0u && ep_pp != 0u)) {
                 // (a lane whose own choice differs joins if the epoch's period suits its list as well)
-                if (ep_pp % q == 0u && ep_pp >= P.pmin() && (want_p == ep_pp || hist.lag(ep_pp)) && in.per_hi - i >= 4u * ep_pp + WALK_TAIL) {
+                if (divides_small(q, ep_pp) && ep_pp >= P.pmin() && (want_p == ep_pp || hist.lag(ep_pp)) && in.per_hi - i >= 4u * ep_pp + WALK_TAIL) {
                     begin = true; P.set_pp(ep_pp); P.set_phase(1u); P.set_pk(0u); P.set_nper(0u); stable = false; sb_n = n_cur;
                     if (stats) stats->probes++;
                 }
