@@ -63,7 +63,7 @@ def test_no_cpu_fallback():
 
 def test_register_budget_of_the_built_kernels():
     """The region pass shares SIMDs with walk waves (512 VGPRs each): its streaming kernel must stay within 40 VGPRs (an allocation of 40,
-    not 48) and the one-cell walk within 168, or one region wave fewer fits beside two walk waves.  Read from the build's own resource
+    not 48) and the one-cell walk within 176 (2 x 176 + 4 x 40 = 512), or one region wave fewer fits beside two walk waves.  Read from the build's own resource
     remarks (csrc/Makefile keeps them and fails the build on the first of the two)."""
     import re
     csrc = os.path.join(os.path.dirname(capi.LIB_PATH))
@@ -79,4 +79,4 @@ def test_register_budget_of_the_built_kernels():
     region = vgprs("regions.log", "region_scan_kernelILi0ELi2ELb0E")
     assert region and max(region) <= 40, region
     walk1 = vgprs("walk_k1.log", "walk_kernelILi1E")
-    assert walk1 and max(walk1) <= 168, walk1
+    assert walk1 and max(walk1) <= 176, walk1
