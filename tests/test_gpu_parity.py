@@ -285,11 +285,13 @@ MFA_AUTOS = [a for a in MANIFEST["automata"] if not a["name"].startswith("nfa_")
 def test_periodic_fuzz_against_oracle(auto, monkeypatch):
     """Every memory automaton of the fixture set (plain, -bnf, -reverse images and the extra regexes, up to
     three cells) on periodic inputs, against the CPU restatement: the library's default engine and the table-driven walk (whose probe
-    control decides where jumps are tried: shape history, optimistic and chained dual periods).  MFA_FUZZ_SEEDS=n: n more seeds, longer strings."""
+    control decides where jumps are tried: shape history, optimistic and chained dual periods).  MFA_FUZZ_SEEDS=n: n more seeds, longer strings
+    (MFA_FUZZ_FIRST=k: seeds k .. k + n)."""
     blob = image.blob_from_dump(oracle_lib.load_dump(auto["name"]))
     alphabet = b"abcd" if "d" in auto["regex"] else b"abc"
     ora = oracle_lib.OracleImage(blob)
-    for seed in range(1 + int(os.environ.get("MFA_FUZZ_SEEDS", "0"))):
+    first_seed = int(os.environ.get("MFA_FUZZ_FIRST", "0"))
+    for seed in range(first_seed, first_seed + 1 + int(os.environ.get("MFA_FUZZ_SEEDS", "0"))):
         rng = np.random.default_rng((int.from_bytes(auto["name"].encode(), "little") + 7919 * seed) % (2 ** 32))
         strings = _periodic_fuzz(rng, 128, 2500 if seed == 0 else 12000, alphabet)
         want = ora.match(strings)
