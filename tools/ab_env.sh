@@ -8,6 +8,6 @@ for r in 1 2 3; do
     env $e timeout -k 10 300 python bench.py --no-secondary --no-cpu-baseline --steps 20 --warmup 6 2> /dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']
-print('%-44s value %.0f GB/s  ms/step %.3f  frac %.3f' % ('$spec', d['value'], d['ms_per_step'], r['frac']), flush=True)"
+print('%-44s value %.0f GB/s  ms/step %.3f  frac %.3f  kernels %.3f ms  gap %.3f ms' % ('$spec', d['value'], d['ms_per_step'], r['frac'], 1e3 * r.get('kernel_seconds_per_step', 0), d['ms_per_step'] - 1e3 * r.get('kernel_seconds_per_step', 0)), flush=True)"
   done
 done
