@@ -620,6 +620,75 @@ def test_mixed_batch_in_one_call(monkeypatch):
         assert np.array_equal(got, want), layout[k]
 
 
+def test_mixed_call_with_more_launches_than_slots_is_refused_before_it_starts(monkeypatch):
+    """a mixed object's launch slots (24) can run out -- 26 segments whose automata alternate between one and two cells
+    are 26 launches.  The call plans before it queues anything: it returns MFA_ERR_UNSUPPORTED, the result buffer is untouched, and the
+    same object then matches a batch that needs few launches (the other segments empty), against the oracle."""
+    import torch
+    from mfa_amd import corpus
+    monkeypatch.setenv("MFA_WALK", "table")
+    monkeypatch.setenv("MFA_MIXED_CUTS", "")
+    dev = torch.device("cuda", 0)
+    layout = [1, 3] * 13
+    n_per = 200
+    blobs = {ex: image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex)) for ex in (1, 3)}
+    images = [capi.Image(blobs[ex]) for ex in layout]
+    mx = capi.Mixed(images)
+    parts_b, parts_o, seg, pos_b, hosts = [], [], [0], 0, []
+    for ex in layout:
+        sizes = corpus.pump_sizes(n_per, 0x5EED0051 + ex + len(seg), 64, 1500)
+        ws = (np.arange(n_per) % 2) == 0
+        b, o = corpus.device_batch(ex, sizes, ws, dev)
+        nb = int(o[-1].item())
+        parts_b.append(b[:nb]); parts_o.append(o[:-1] + pos_b); pos_b += nb; seg.append(seg[-1] + n_per)
+        hosts.append(corpus.host_strings(ex, sizes, ws))
+    bytes_all = torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=dev)])
+    off_all = torch.cat(parts_o + [torch.tensor([pos_b], dtype=torch.int64, device=dev)])
+    out = torch.full((seg[-1],), 7, dtype=torch.uint8, device=dev)
+    with pytest.raises(capi.MfaError) as err:
+        mx.match_tensors(bytes_all, off_all, seg, d_results=out)
+    assert err.value.code == capi.ERR_UNSUPPORTED
+    torch.cuda.synchronize()
+    assert int((out != 7).sum().item()) == 0                      # nothing was started
+    # the first four segments only: the 22 others are empty (seg_first repeats), four launches
+    n4 = seg[4]
+    seg4 = seg[:5] + [n4] * (len(seg) - 5)
+    res = mx.match_tensors(bytes_all, off_all[:n4 + 1], seg4).clone()
+    torch.cuda.synchronize()
+    for k in range(4):
+        want = oracle_lib.OracleImage(blobs[layout[k]]).match(hosts[k])
+        assert np.array_equal(res[seg[k]:seg[k + 1]].cpu().numpy(), want), k
+    mx.close()
+
+
+def test_spill_budget_shrinks_the_grid_or_refuses(monkeypatch):
+    """the walk's spill areas are sized per wave of the grid for the worst case and bounded by a byte budget
+    (MFA_WALK_SPILL_MB, 2 GiB by default): a small budget means fewer (persistent) waves and the same answers; a budget that not even one
+    workgroup fits is MFA_ERR_NOMEM, not a failed allocation somewhere inside.  The 77-node automaton: lists of 10 entries, most of them spilled."""
+    import torch
+    from mfa_amd import corpus
+    monkeypatch.setenv("MFA_WALK", "table")
+    dev = torch.device("cuda", 0)
+    blob = image.blob_from_dump(oracle_lib.load_dump("ex8_reverse"))
+    n = 1500
+    sizes = corpus.pump_sizes(n, 0x5EED0061, 64, 1200)
+    ws = (np.arange(n) % 2) == 0
+    b, o = corpus.device_batch(8, sizes, ws, dev)
+    want = oracle_lib.OracleImage(blob).match(corpus.host_strings(8, sizes, ws))
+    for mb in ("2048", "8"):
+        monkeypatch.setenv("MFA_WALK_SPILL_MB", mb)
+        img = capi.Image(blob)
+        got = img.match_tensors(b, o).cpu().numpy()
+        assert np.array_equal(got, want), mb
+        img.close()
+    monkeypatch.setenv("MFA_WALK_SPILL_MB", "1")
+    img = capi.Image(blob)
+    with pytest.raises(capi.MfaError) as err:
+        img.match_tensors(b, o)
+    assert err.value.code == capi.ERR_NOMEM
+    img.close()
+
+
 def test_mixed_batch_default_grouping_reads_the_size_once(monkeypatch):
     """Without MFA_MIXED_CUTS the call chooses its groups from the batch's bytes, which it reads back on the first call with a string
     count it has not met (waiting for the caller's stream) and remembers: first and second call, on a side stream with work pending, must
