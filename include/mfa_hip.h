@@ -135,8 +135,10 @@ int  mfa_match_batch_regions(mfa_image_t* img, const uint8_t* d_bytes, const uin
  * device; the images must outlive it, scan in the same direction and fit the table-driven walk
  * (MFA_ERR_UNSUPPORTED otherwise).  One call runs the region pass over the batch in a few groups of
  * consecutive segments and walks each group -- all its automata in ONE launch, any lane any automaton --
- * as soon as its regions are known, on internal streams: the walk of a group runs beside the region
- * pass of the next: one region launch per group, the walks wait for the event behind it.  (MFA_MIXED_GATE=1, table-driven
+ * as soon as its regions are known: the region launches go to `stream` itself, the walks to internal streams, so that
+ * the walk of a group runs beside the region pass of the next (one region launch per group, the walks wait for the event
+ * behind it).  Calls on one object are ordered one behind the other, also when they come on different streams (the object's
+ * table and work areas are shared).  (MFA_MIXED_GATE=1, table-driven
  * walk only: the region pass is ONE launch over the whole batch; it counts every finished string for its group, a
  * one-wave kernel in front of a group's walk launches ends when the group is complete, and every word of a table row
  * carries the call's stamp, so that a walk never takes a row that has not arrived yet -- or a stale copy of an earlier
@@ -171,6 +173,11 @@ int  mfa_mixed_timing(mfa_mixed_t* mx, int device, uint32_t back, float* region_
 /* what the last call on `device` launched (any pointer may be NULL): region launches (1 when the walks are released by counters),
  * walk launches, groups of strings, and gated = 1 if the walks were released by counters, 0 if by events */
 int  mfa_mixed_last_launches(mfa_mixed_t* mx, int device, uint32_t* region_launches, uint32_t* walk_launches, uint32_t* groups, uint32_t* gated);
+
+/* The result vector of a batch as a bitmap: bit k % 8 of byte k / 8 of d_bitmap ((n + 7) / 8 bytes, device memory) = string k was accepted
+ * (result code 1).  Asynchronous on `stream`.  What a process sends when the results of a batch sharded over several GPUs are gathered
+ * (the reference matches one string at a time and has no such step: matchers/match_mfa.cpp:28-36 prints each answer as it comes). */
+int  mfa_pack_result_bitmap(const uint8_t* d_results, uint64_t n, uint8_t* d_bitmap, void* stream);
 
 /* Same with HOST pointers: copies the batch to the device, matches, copies the
  * results back, synchronises.  Convenience for callers that hold std::strings

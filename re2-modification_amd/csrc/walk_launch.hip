@@ -207,7 +207,8 @@ struct mfa_mixed {
     std::map<uint64_t, uint64_t> bytes_of;                     // string count of a batch -> its bytes (read back once, see mfa_match_mixed)
     struct Dev {
         uint32_t* d_tables = nullptr;
-        hipStream_t rs = nullptr;                              // region stream
+        hipStream_t rs = nullptr;                              // region stream (the gate; MFA_MIXED_REGION_ON_CALLER=0)
+        hipStream_t last_cs = nullptr;                         // the caller's stream of the last call
         hipStream_t ws[MIX_MAX_STREAMS] = {nullptr};           // walk streams
         hipEvent_t ev_g[MIX_MAX_GROUPS] = {nullptr};           // group g's regions are known (timed)
         hipEvent_t ev_w[MIX_MAX_STREAMS] = {nullptr};          // end of a walk stream's work
@@ -275,6 +276,7 @@ void mfa_mixed_destroy(mfa_mixed_t* mx) {
         mfa_mixed::Dev& d = kv.second;
         if (d.rs) (void)hipStreamSynchronize(d.rs);
         for (hipStream_t w : d.ws) if (w) (void)hipStreamSynchronize(w);
+        if (d.calls > 0) (void)hipEventSynchronize(d.ev_end[(d.calls - 1) % MIX_TIMINGS]);      // (region launches on a caller's stream)
         if (d.d_tables) (void)hipFree(d.d_tables);
         if (d.d_regions) (void)hipFree(d.d_regions);
         for (uint32_t* p : d.d_spill) if (p) (void)hipFree(p);
@@ -422,6 +424,8 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
     // ms in two / three / four groups: a walk launch is latency-bound, its 0.15 ms are paid per group and hide behind nothing that short.)
     if (ns == 1 && ng == 1 && env_int("MFA_MIXED_SINGLE_DIRECT", 1) != 0) {
         const uint32_t slot1 = (uint32_t)(d->calls % MIX_TIMINGS);
+        if (d->calls > 0 && d->last_cs != cs) HIP_TRY(hipStreamWaitEvent(cs, d->ev_end[(d->calls - 1) % MIX_TIMINGS], 0));
+        d->last_cs = cs;
         HIP_TRY(hipEventRecord(d->ev_r0[slot1], cs));
         rc = mfa_match_batch(mx->images[0], d_bytes, d_offsets, n, d_results, device, stream);
         HIP_TRY(hipEventRecord(d->ev_r1[slot1], cs));
@@ -488,24 +492,32 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
             else HIP_TRY(hipStreamCreateWithFlags(&d->ws[k], hipStreamNonBlocking));
         }
     const uint32_t slot_t = (uint32_t)(d->calls % MIX_TIMINGS);
+    // The region launches go to the CALLER's stream (MFA_MIXED_REGION_ON_CALLER=0, or the gate: to a stream of the object's own): back-to-back calls
+    // then pass from the last walk of one to the first region launch of the next through ONE event (walk stream -> caller's stream) instead of
+    // three (walk stream -> region stream -> caller's stream -> region stream): 0.02 ms a call.
+    hipStream_t const rs = (!gate && env_int("MFA_MIXED_REGION_ON_CALLER", 1) != 0) ? cs : d->rs;
 
     // ---- from here on work goes to the internal streams.  Whatever happens, the caller's stream is made to wait for all of it before this
     // function returns: a caller that gets an error may free or reuse its buffers in stream order like one that gets MFA_OK.
     struct Join {
-        mfa_mixed::Dev* d; hipStream_t cs; int NW; uint32_t slot_t; bool used[MIX_MAX_STREAMS] = {false}; bool started = false; int err = MFA_OK;
+        mfa_mixed::Dev* d; hipStream_t cs, rs; int NW; uint32_t slot_t; bool used[MIX_MAX_STREAMS] = {false}; bool started = false; int err = MFA_OK;
         void run() {
             if (!started) return;
             started = false;
             for (int k = 0; k < NW; k++)
                 if (used[k]) {
-                    if (hipEventRecord(d->ev_w[k], d->ws[k]) != hipSuccess || hipStreamWaitEvent(d->rs, d->ev_w[k], 0) != hipSuccess) { err = MFA_ERR_HIP; (void)hipStreamSynchronize(d->ws[k]); }
+                    if (hipEventRecord(d->ev_w[k], d->ws[k]) != hipSuccess || hipStreamWaitEvent(rs, d->ev_w[k], 0) != hipSuccess) { err = MFA_ERR_HIP; (void)hipStreamSynchronize(d->ws[k]); }
                 }
-            if (hipEventRecord(d->ev_end[slot_t], d->rs) != hipSuccess || hipStreamWaitEvent(cs, d->ev_end[slot_t], 0) != hipSuccess) { err = MFA_ERR_HIP; (void)hipStreamSynchronize(d->rs); }
+            if (hipEventRecord(d->ev_end[slot_t], rs) != hipSuccess || (rs != cs && hipStreamWaitEvent(cs, d->ev_end[slot_t], 0) != hipSuccess)) { err = MFA_ERR_HIP; (void)hipStreamSynchronize(rs); }
         }
         ~Join() { run(); }
-    } join{d, cs, NW, slot_t};
+    } join{d, cs, rs, NW, slot_t};
+    // (the object's buffers -- table, counters, spill areas -- are shared by its calls: with the region launches on an internal stream the calls
+    // follow each other there; on callers' streams a call starts behind the end of the one before it, whichever stream that one came on)
+    if (d->calls > 0 && d->last_cs != cs) HIP_TRY(hipStreamWaitEvent(rs, d->ev_end[(d->calls - 1) % MIX_TIMINGS], 0));
+    d->last_cs = cs;
     HIP_TRY(hipEventRecord(d->ev_in, cs));
-    HIP_TRY(hipStreamWaitEvent(d->rs, d->ev_in, 0));
+    if (rs != cs) HIP_TRY(hipStreamWaitEvent(rs, d->ev_in, 0));
     join.started = true;
     if (gate) {
         // the gate header in front of the table (regions.hip: gate_signal), the counters back to zero; the walk streams start behind both
@@ -513,15 +525,15 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
         for (uint32_t k = 0; k < MFA_GATE_FIXED_WORDS; k++) h[k] = 0ull;
         for (uint32_t k = 0; k < MFA_GATE_MAX_GROUPS; k++) h[MFA_GATE_FIXED_WORDS - 1 - k] = k < ng ? cut[k + 1] : ~0ull;
         h[MFA_GATE_FIXED_WORDS - 33] = (uint64_t)stamp << 52;
-        HIP_TRY(hipMemsetAsync(d->d_regions, 0, (MFA_GATE_HEADER_WORDS - MFA_GATE_FIXED_WORDS) * sizeof(uint64_t), d->rs));      // the counters
-        HIP_TRY(hipMemcpyAsync(d->d_regions + (MFA_GATE_HEADER_WORDS - MFA_GATE_FIXED_WORDS), h, MFA_GATE_FIXED_WORDS * sizeof(uint64_t), hipMemcpyHostToDevice, d->rs));
-        HIP_TRY(hipEventRecord(d->ev_clear, d->rs));
+        HIP_TRY(hipMemsetAsync(d->d_regions, 0, (MFA_GATE_HEADER_WORDS - MFA_GATE_FIXED_WORDS) * sizeof(uint64_t), rs));      // the counters
+        HIP_TRY(hipMemcpyAsync(d->d_regions + (MFA_GATE_HEADER_WORDS - MFA_GATE_FIXED_WORDS), h, MFA_GATE_FIXED_WORDS * sizeof(uint64_t), hipMemcpyHostToDevice, rs));
+        HIP_TRY(hipEventRecord(d->ev_clear, rs));
     }
     for (int k = 0; k < NW; k++) HIP_TRY(hipStreamWaitEvent(d->ws[k], gate ? d->ev_clear : d->ev_in, 0));
-    HIP_TRY(hipEventRecord(d->ev_r0[slot_t], d->rs));
+    HIP_TRY(hipEventRecord(d->ev_r0[slot_t], rs));
     uint32_t region_launches = 0;
     if (gate) {
-        rc = launch_region_scan(d->n_cus, d_bytes, d_offsets, n, d_table, d->rs, 128u, true);
+        rc = launch_region_scan(d->n_cus, d_bytes, d_offsets, n, d_table, rs, 128u, true);
         if (rc != MFA_OK) return rc;
         region_launches = 1;
     }
@@ -529,11 +541,11 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
     for (uint32_t g = 0; g < ng; g++) {
         const uint64_t lo = cut[g], hi = cut[g + 1];
         if (with_regions && !gate) {
-            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d_table + lo * MFA_REGION_WORDS, d->rs, table ? 128u : 256u);
+            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d_table + lo * MFA_REGION_WORDS, rs, table ? 128u : 256u);
             if (rc != MFA_OK) return rc;
             region_launches++;
         }
-        if (!gate) HIP_TRY(hipEventRecord(d->ev_g[g], d->rs));
+        if (!gate) HIP_TRY(hipEventRecord(d->ev_g[g], rs));
         bool waits[MIX_MAX_STREAMS] = {false};
         // a stream's first launch of this group waits for the group's regions: for the event behind its region launch, or -- with the gate -- for
         // one wave, launched in front of it, that ends when the region kernel has counted every string of the group
@@ -577,7 +589,7 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
             }
         }
     }
-    HIP_TRY(hipEventRecord(d->ev_r1[slot_t], d->rs));
+    HIP_TRY(hipEventRecord(d->ev_r1[slot_t], rs));
     // the caller's stream (and the call's end event, on the region stream) wait for every stream that was given work
     join.run();
     if (join.err != MFA_OK) return join.err;

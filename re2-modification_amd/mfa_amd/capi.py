@@ -18,7 +18,7 @@ EXPORTS = ["mfa_image_create", "mfa_image_destroy", "mfa_image_get_info", "mfa_i
            "mfa_match_batch_regions", "mfa_region_scan", "mfa_match_batch_host", "mfa_last_kernel_ms", "mfa_last_region_ms",
            "mfa_device_count", "mfa_last_hip_error", "mfa_strerror", "mfa_version",
            "mfa_mixed_create", "mfa_mixed_destroy", "mfa_match_mixed", "mfa_match_mixed_sized", "mfa_match_mixed_host", "mfa_mixed_last_ms", "mfa_mixed_timing",
-           "mfa_mixed_last_launches"]
+           "mfa_mixed_last_launches", "mfa_pack_result_bitmap"]
 
 REGION_WORDS, REGION_MAX, REGION_OVERFLOW, REGION_MIN_LEN = 16, 15, 0x100, 64
 
@@ -74,6 +74,7 @@ def lib():
         L.mfa_match_mixed.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32, vp]
         L.mfa_match_mixed_sized.argtypes = [vp, vp, vp, u64, u64, ctypes.POINTER(u64), vp, i32, vp]
         L.mfa_mixed_last_launches.argtypes = [vp, i32] + [ctypes.POINTER(ctypes.c_uint32)] * 4
+        L.mfa_pack_result_bitmap.argtypes = [vp, u64, vp, vp]
         L.mfa_match_mixed_host.argtypes = [vp, vp, vp, u64, ctypes.POINTER(u64), vp, i32]
         L.mfa_mixed_last_ms.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
         L.mfa_mixed_timing.argtypes = [vp, i32, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float)]
@@ -238,6 +239,17 @@ def region_scan(d_bytes, d_offsets, d_table=None, stream=None):
     _check(lib().mfa_region_scan(d_bytes.data_ptr(), d_offsets.data_ptr(), n, d_table.data_ptr(), dev,
                                  ctypes.c_void_p(s.cuda_stream)), "mfa_region_scan")
     return d_table
+
+
+def pack_result_bitmap(d_results, d_bitmap=None, stream=None):
+    """mfa_pack_result_bitmap on a torch CUDA uint8 result vector: uint8 bitmap ((n + 7) // 8), bit k % 8 of byte k // 8 = string k accepted."""
+    import torch
+    n = d_results.numel()
+    if d_bitmap is None:
+        d_bitmap = torch.empty((n + 7) // 8, dtype=torch.uint8, device=d_results.device)
+    s = stream if stream is not None else torch.cuda.current_stream(d_results.device)
+    _check(lib().mfa_pack_result_bitmap(d_results.data_ptr(), n, d_bitmap.data_ptr(), ctypes.c_void_p(s.cuda_stream)), "mfa_pack_result_bitmap")
+    return d_bitmap
 
 
 def device_count():

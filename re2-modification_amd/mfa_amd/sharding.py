@@ -6,6 +6,8 @@ image, and the only exchange is a gather of the per-rank result bitmaps to rank 
 GPUs -- torch.distributed backend "nccl" -- or gloo on CPUs in the tests).  No collective runs inside
 the match.  Order is restored from the partition: rank r's bits are strings cuts[r] .. cuts[r+1]-1.
 """
+import os
+
 import numpy as np
 
 
@@ -28,6 +30,9 @@ def pack_bitmap(results):
     (ceil(n/8)), bit k%8 of byte k//8 = string k accepted.  Only the value 1 sets a bit; count_unmatched() reports the 2s."""
     import torch
     n = results.numel()
+    if results.is_cuda and results.is_contiguous() and n and os.environ.get("MFA_TORCH_PACK", "") != "1":
+        from . import capi                                   # one kernel of the library instead of five of torch's (behind every step of a batch)
+        return capi.pack_result_bitmap(results)
     r = (results == 1).to(torch.uint8)
     pad = (-n) % 8
     if pad:

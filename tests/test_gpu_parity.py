@@ -689,6 +689,45 @@ def test_spill_budget_shrinks_the_grid_or_refuses(monkeypatch):
     img.close()
 
 
+def test_mixed_calls_on_two_streams_share_one_object(monkeypatch):
+    """One mfa_mixed object, calls alternating between two caller streams with nothing but stream order between them: the object's table,
+    counters and spill areas are shared, so a call must start behind the end of the one before it whichever stream that came on (the region
+    launches run on the CALLER's stream).  Two batches of different content and size; every call's answers against the single-automaton entry
+    point's."""
+    import torch
+    from mfa_amd import corpus
+    monkeypatch.setenv("MFA_WALK", "table")
+    monkeypatch.delenv("MFA_MIXED_CUTS", raising=False)
+    dev = torch.device("cuda", 0)
+    blobs = [image.blob_from_dump(oracle_lib.load_dump("ex%d_plain" % ex)) for ex in (1, 6, 8)]
+    images = [capi.Image(b) for b in blobs]
+    batches = []
+    for seed, n_per, hi in ((0x5EED0081, 30000, 6000), (0x5EED0082, 23000, 9000)):
+        parts_b, parts_o, seg, pos_b = [], [], [0], 0
+        for ex in (1, 6, 8):
+            sizes = corpus.pump_sizes(n_per, seed + ex, 64, hi)
+            b, o = corpus.device_batch(ex, sizes, (np.arange(n_per) % 2) == 0, dev)
+            nb = int(o[-1].item())
+            parts_b.append(b[:nb]); parts_o.append(o[:-1] + pos_b); pos_b += nb; seg.append(seg[-1] + n_per)
+        bytes_all = torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=dev)])
+        off_all = torch.cat(parts_o + [torch.tensor([pos_b], dtype=torch.int64, device=dev)])
+        want = torch.cat([images[k].match_tensors(bytes_all, off_all[seg[k]:seg[k + 1] + 1]).clone() for k in range(3)])
+        batches.append((bytes_all, off_all, seg, want))
+    torch.cuda.synchronize()
+    mx = capi.Mixed(images)
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    outs = []
+    for call in range(8):
+        bytes_all, off_all, seg, want = batches[call % 2]
+        out = torch.full((seg[-1],), 7, dtype=torch.uint8, device=dev)
+        mx.match_tensors(bytes_all, off_all, seg, d_results=out, stream=streams[(call // 2 + call) % 2])
+        outs.append((out, want))
+    torch.cuda.synchronize()
+    for call, (out, want) in enumerate(outs):
+        assert torch.equal(out, want), call
+    mx.close()
+
+
 def test_mixed_batch_default_grouping_reads_the_size_once(monkeypatch):
     """Without MFA_MIXED_CUTS the call chooses its groups from the batch's bytes, which it reads back on the first call with a string
     count it has not met (waiting for the caller's stream) and remembers: first and second call, on a side stream with work pending, must

@@ -73,3 +73,22 @@ def test_bitmap_ignores_unmatched_code():
     bm = sharding.pack_bitmap(r)
     assert torch.equal(sharding.unpack_bitmap(bm, 10), (r == 1).to(torch.uint8))
     assert sharding.count_unmatched(r) == 4
+
+
+@pytest.mark.gpu
+def test_result_bitmap_kernel_against_the_tensor_form(monkeypatch):
+    """mfa_pack_result_bitmap (what pack_bitmap uses for device tensors) against the tensor-library form of the same definition: ragged
+    counts, a result vector that does not start at an 8-byte boundary, codes 0 / 1 / 2, and the round trip."""
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(0x5EED0071)
+    base = torch.randint(0, 3, (100003,), dtype=torch.uint8, device=dev, generator=g)
+    for lo, n in ((0, 1), (0, 7), (0, 8), (0, 9), (0, 4096), (3, 65537), (5, 99991), (0, 100003), (1, 63)):
+        r = base[lo:lo + n]
+        monkeypatch.setenv("MFA_TORCH_PACK", "1")
+        want = sharding.pack_bitmap(r)
+        monkeypatch.delenv("MFA_TORCH_PACK")
+        got = sharding.pack_bitmap(r)
+        torch.cuda.synchronize()
+        assert got.dtype == torch.uint8 and got.numel() == (n + 7) // 8
+        assert torch.equal(got, want), (lo, n)
+        assert torch.equal(sharding.unpack_bitmap(got, n), (r == 1).to(torch.uint8)), (lo, n)
