@@ -113,7 +113,7 @@ int launch_dfa_walk(const HostImage& img, DeviceState& ds, LaunchCtx& cx, const 
 constexpr uint32_t MFA_GATE_MAX_GROUPS = 32;
 constexpr size_t MFA_GATE_FIXED_WORDS = 3 * MFA_GATE_MAX_GROUPS;                                  // the groups' ends, the call's stamp (regions.hip: gate_signal)
 constexpr size_t MFA_GATE_HEADER_WORDS = MFA_GATE_FIXED_WORDS + MFA_GATE_MAX_GROUPS * 64 * 8;      // + a 64-byte line per (group, residue mod 64)      // u64 words in front of the table (a multiple of 16: the rows stay 128-byte aligned)
-int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream, unsigned threads = 256, bool gate = false);
+int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream, unsigned threads = 256, bool gate = false, void* done_event = nullptr);
 int launch_gate_wait(const uint64_t* d_table, uint32_t group, void* stream);      // one wave that ends when the gated region launch has counted every string of `group`
 // launch contexts (capi.hip); the caller holds the image mutex
 int  ctx_acquire(DeviceState& ds, void* stream, LaunchCtx** out);
@@ -136,7 +136,7 @@ void device_release(DeviceState& ds);
 struct WalkPlanInput { uint32_t K, max_live; bool reversed; uint32_t table_words; };
 int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                 uint8_t* d_results, const uint64_t* d_regions, uint32_t n_seg, const uint32_t* seg_first, const uint32_t* seg_table,
-                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate = 0, LeanHint* lean = nullptr);
+                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate = 0, LeanHint* lean = nullptr, void* wait_event = nullptr);
 int  walk_mode();          // MFA_WALK: 0 auto (default), 1 table, 2 jit
 void set_last_hip_error(int e);
 

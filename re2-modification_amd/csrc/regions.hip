@@ -35,6 +35,7 @@
 // The block test is twelve V_QSAD_PK_U16_U8 (all eight periods at once, see block_mask); a row whose
 // 64 blocks all look like the previous row's costs one compare and one ballot more.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdint>
 #include <cstdlib>
@@ -620,8 +621,8 @@ __global__ void __launch_bounds__(256, 8) region_scan_kernel(const uint8_t* __re
     }
 }
 
-int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream, unsigned threads, bool gate) {
-    if (n == 0) return MFA_OK;
+int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n, uint64_t* d_table, void* stream, unsigned threads, bool gate, void* done_event) {
+    if (n == 0) { if (done_event) HIP_TRY(hipEventRecord((hipEvent_t)done_event, (hipStream_t)stream)); return MFA_OK; }
     hipStream_t s = (hipStream_t)stream;
     const char* em = getenv("MFA_REGION_MODE");                   // development knobs
     const int mode = em ? atoi(em) : 0;
@@ -649,11 +650,14 @@ int launch_region_scan(int n_cus, const uint8_t* d_bytes, const uint64_t* d_offs
     if (gate) hipLaunchKernelGGL((region_scan_kernel<0, 2, false, true>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else if (mode == 1) hipLaunchKernelGGL((region_scan_kernel<1, kRegionDepth, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else if (safe) hipLaunchKernelGGL((region_scan_kernel<0, 2, true>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
+    // (done_event: the event is the launch's own completion signal -- no packet of its own between this launch and the next one on the stream)
+    else if (depth == 2 && done_event) hipExtLaunchKernelGGL((region_scan_kernel<0, 2, false>), dim3((unsigned)blocks), dim3(block), lds, s, nullptr, (hipEvent_t)done_event, 0u, d_bytes, d_offsets, n, d_table, rotate);
     else if (depth == 2) hipLaunchKernelGGL((region_scan_kernel<0, 2, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else if (depth == 4) hipLaunchKernelGGL((region_scan_kernel<0, 4, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else if (depth == 3) hipLaunchKernelGGL((region_scan_kernel<0, 3, false>), dim3((unsigned)blocks), dim3(block), lds, s, d_bytes, d_offsets, n, d_table, rotate);
     else return MFA_ERR_UNSUPPORTED;
     HIP_TRY(hipGetLastError());
+    if (done_event && !(depth == 2 && !gate && mode != 1 && !safe)) HIP_TRY(hipEventRecord((hipEvent_t)done_event, s));
     return MFA_OK;
 }
 

@@ -44,8 +44,8 @@ static size_t wave_words(uint32_t K, uint32_t C, bool ig, uint32_t nm_words = 0)
 // longest possible list if that leaves room for two workgroups per CU, else what does (longer lists spill to `d_spill`).
 int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, const uint8_t* d_bytes, const uint64_t* d_offsets, uint64_t n,
                 uint8_t* d_results, const uint64_t* d_regions, uint32_t n_seg, const uint32_t* seg_first, const uint32_t* seg_table,
-                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate, LeanHint* lean) {
-    if (n == 0) return MFA_OK;
+                uint32_t** d_spill, size_t* spill_bytes, unsigned long long* d_counter, void* stream, uint32_t gate, LeanHint* lean, void* wait_event) {
+    if (n == 0) { if (wait_event) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_event, 0)); return MFA_OK; }
     if (n_seg == 0 || n_seg > WALK_MAX_SEG || n > 0xffffffffull) return MFA_ERR_INVALID_ARG;
     WalkLaunch L;
     WalkArgs& a = L.args;
@@ -154,6 +154,8 @@ int launch_walk(const WalkPlanInput& p, const uint32_t* d_tables, int n_cus, con
     const bool stats = getenv("MFA_WALK_STATS") != nullptr && p.K == 1;
     if (stats) { a.lean_queue = nullptr; L.lean_grid = 0; }
     HIP_TRY(hipMemsetAsync(d_counter, 0, sizeof(unsigned long long) * (stats ? 32 : 3), (hipStream_t)stream));      // ticket counter, queue length, the lean kernel's tickets
+    // (what the launch waits for -- its group's regions -- comes AFTER its own preparations on the stream: they are done when the event arrives)
+    if (wait_event) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)wait_event, 0));
     if (stats) {
         rc = launch_walk_stats(L, stream);
         if (rc == MFA_OK) { (void)hipStreamSynchronize((hipStream_t)stream); walk_print_stats(d_counter, "walk"); }
@@ -514,7 +516,7 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
     } join{d, cs, rs, NW, slot_t};
     // (the object's buffers -- table, counters, spill areas -- are shared by its calls: with the region launches on an internal stream the calls
     // follow each other there; on callers' streams a call starts behind the end of the one before it, whichever stream that one came on)
-    if (d->calls > 0 && d->last_cs != cs) HIP_TRY(hipStreamWaitEvent(rs, d->ev_end[(d->calls - 1) % MIX_TIMINGS], 0));
+    if (d->calls > 0 && d->last_cs != cs) HIP_TRY(hipStreamWaitEvent(cs, d->ev_end[(d->calls - 1) % MIX_TIMINGS], 0));      // (the walk streams start behind ev_in: below)
     d->last_cs = cs;
     HIP_TRY(hipEventRecord(d->ev_in, cs));
     if (rs != cs) HIP_TRY(hipStreamWaitEvent(rs, d->ev_in, 0));
@@ -532,6 +534,7 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
     for (int k = 0; k < NW; k++) HIP_TRY(hipStreamWaitEvent(d->ws[k], gate ? d->ev_clear : d->ev_in, 0));
     HIP_TRY(hipEventRecord(d->ev_r0[slot_t], rs));
     uint32_t region_launches = 0;
+    const bool ext_events = table && !gate && env_int("MFA_MIXED_EXT_EVENTS", 1) != 0;      // a group's event = its region launch's completion signal
     if (gate) {
         rc = launch_region_scan(d->n_cus, d_bytes, d_offsets, n, d_table, rs, 128u, true);
         if (rc != MFA_OK) return rc;
@@ -541,11 +544,11 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
     for (uint32_t g = 0; g < ng; g++) {
         const uint64_t lo = cut[g], hi = cut[g + 1];
         if (with_regions && !gate) {
-            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d_table + lo * MFA_REGION_WORDS, rs, table ? 128u : 256u);
+            rc = launch_region_scan(d->n_cus, d_bytes, d_offsets + lo, hi - lo, d_table + lo * MFA_REGION_WORDS, rs, table ? 128u : 256u, false, ext_events ? d->ev_g[g] : nullptr);
             if (rc != MFA_OK) return rc;
             region_launches++;
         }
-        if (!gate) HIP_TRY(hipEventRecord(d->ev_g[g], rs));
+        if (!gate && !(with_regions && ext_events)) HIP_TRY(hipEventRecord(d->ev_g[g], rs));
         bool waits[MIX_MAX_STREAMS] = {false};
         // a stream's first launch of this group waits for the group's regions: for the event behind its region launch, or -- with the gate -- for
         // one wave, launched in front of it, that ends when the region kernel has counted every string of the group
@@ -559,15 +562,19 @@ static int match_mixed_impl(mfa_mixed_t* mx, const uint8_t* d_bytes, const uint6
         if (table) {
             for (const MixLaunch& L : plan) {
                 if (L.g != g) continue;
-                rc = release(L.k);
-                if (rc != MFA_OK) return rc;
+                void* wait_for = nullptr;                       // (without the gate the launch itself waits, behind its own preparations on the stream)
+                if (!gate && !waits[L.k]) { waits[L.k] = true; wait_for = d->ev_g[g]; }
+                else {
+                    rc = release(L.k);
+                    if (rc != MFA_OK) return rc;
+                }
                 uint32_t sf[WALK_MAX_SEG + 1], stb[WALK_MAX_SEG];
                 for (uint32_t j = 0; j <= L.s1 - L.s0; j++) sf[j] = (uint32_t)(std::min(std::max(seg_first[L.s0 + j], L.a), L.b) - L.a);
                 for (uint32_t j = 0; j < L.s1 - L.s0; j++) stb[j] = mx->block_at[L.s0 + j] - L.w0;
                 const WalkPlanInput pk{L.Kc, L.ml, mx->reversed, L.w1 - L.w0};
                 join.used[L.k] = true;
                 rc = launch_walk(pk, d->d_tables + L.w0, d->n_cus, d_bytes, d_offsets + L.a, L.b - L.a, d_results + L.a, d_table ? d_table + L.a * MFA_REGION_WORDS : nullptr,
-                                 L.s1 - L.s0, sf, stb, &d->d_spill[slot], &d->spill_bytes[slot], d->d_counters + 64 * slot, d->ws[L.k], gate ? (0x1000u | stamp) : 0u, &d->lean[slot]);
+                                 L.s1 - L.s0, sf, stb, &d->d_spill[slot], &d->spill_bytes[slot], d->d_counters + 64 * slot, d->ws[L.k], gate ? (0x1000u | stamp) : 0u, &d->lean[slot], wait_for);
                 if (rc != MFA_OK) return rc;
                 slot++;
             }
