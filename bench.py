@@ -110,6 +110,17 @@ def hbm_preflight(n_per, min_len, max_len, world, rank, device_index):
     return need, free
 
 
+def device_facts(device_index):
+    """what the runtime says about rank 0's device (boxes of one pool differ by 8 % on the same build: DESIGN.md section 4.3)"""
+    import torch
+    p = torch.cuda.get_device_properties(device_index)
+    facts = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "compute_units": p.multi_processor_count, "hbm_bytes": p.total_memory}
+    for key in ("clock_rate", "memory_clock_rate", "memory_bus_width", "L2_cache_size"):
+        if hasattr(p, key):
+            facts[key] = getattr(p, key)
+    return facts
+
+
 def load_blob(name):
     from mfa_amd import image
     with open(os.path.join(GOLDEN, "images", name + ".dump")) as f:
@@ -811,6 +822,7 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "ranks_seen": dist.get_world_size() if dist else 1, "backend": (dist.get_backend() if dist else None),
             "bytes_by_rank": bytes_by_rank, "strings_by_rank": counts,
+            "device": device_facts(local),
             "config": {"workload": "10 README MFA examples (plain mode) as ONE mixed batch matched by one mfa_match_mixed call per step, %d pumped attack strings per "
                                    "example%s, pump size log-uniform [%d, %d], alternating with/without suffix "
                                    "(BASELINE configs[3]: 10M strings over 8 GPUs)" % (
